@@ -1,0 +1,141 @@
+/*
+ * nnop_hip.h -- C ABI of libnnop_hip.so: MI355X (gfx950) Flash Attention behind NNop.jl's
+ * operator boundary.
+ *
+ * These are exactly the entry points a Julia package extension of the shape of
+ * ext/NNopAMDGPUExt.jl:1-11 `ccall`s to replace, for ROCArray arguments, the two generic
+ * host functions of the reference:
+ *
+ *   NNop._flash_attention(q,k,v,pair; causal,kpad_mask) -> (o, ms, ls)   src/attention.jl:133-177
+ *   NNop.∇flash_attention(Δ,o,ms,ls,q,k,v,pair; causal,kpad_mask)
+ *                                      -> (dq, dk, dv, dpair|nothing)   src/attention_bwd.jl:199-275
+ *   NNop._shared_memory(backend, device_id) -> UInt64                    ext/NNopAMDGPUExt.jl:6-9
+ *
+ * (binding shown in INTEGRATION.md; shipped, source-only, in nnop.jl_amd/julia/).
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no C++ / torch types cross this boundary.
+ *   - Every pointer is a DEVICE pointer on the current HIP device; the caller owns every
+ *     buffer, outputs and workspace included (replaces the reference's internal
+ *     `similar` / `KA.zeros`, src/attention.jl:166-168, src/attention_bwd.jl:224-238).
+ *   - All tensors dense, contiguous, E fastest -- Julia column-major (E,L,H,B) is the same
+ *     memory as C row-major [B][H][L][E]:
+ *        q,o,dO,dq : [B][QH][QL][E]      k,v,dk,dv : [B][KH][KL][E]
+ *        ms,ls     : [B][QH][QL]         (dtype T, src/attention.jl:167-168)
+ *        pair,dpair: [B][KL][QL][QH]     (Julia (QH,QL,KL,B), src/attention.jl:62)
+ *        kpad_mask : [B][KL], 1 byte per element, nonzero = key is valid (Julia Bool matrix
+ *                    (KL,B), src/attention.jl:76)
+ *   - Launches are asynchronous on the passed stream; nothing synchronises, allocates or
+ *     frees; no pointer is retained after return (src/attention.jl:170-176 never syncs).
+ *   - Re-entrant; no mutable global state.  Safe from concurrent host threads on different
+ *     streams / devices.  The caller selects the device (hipSetDevice) before calling.
+ *   - Errors are returned, never thrown: 0 = success, negative = nnop_status.  The host shim
+ *     re-raises with the reference's messages (src/attention.jl:141-144).
+ */
+#ifndef NNOP_HIP_H
+#define NNOP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element type T of q,k,v,o,ms,ls,pair and all gradients (they share one T,
+ * src/attention.jl:134-137) */
+typedef enum nnop_dtype {
+    NNOP_F32  = 0,
+    NNOP_F16  = 1,
+    NNOP_BF16 = 2
+} nnop_dtype;
+
+typedef enum nnop_status {
+    NNOP_OK                 =  0,
+    NNOP_ERR_EMB_MISMATCH   = -1,  /* "Embedding dim of Q `..` must be the same as of K" (attention.jl:141) */
+    NNOP_ERR_KV_SHAPE       = -2,  /* "Shapes of K and V must be the same"               (attention.jl:142) */
+    NNOP_ERR_EMB_NOT_POW2   = -3,  /* "Only power-of-2 embedding dims are supported."     (attention.jl:143) */
+    NNOP_ERR_HEADS          = -4,  /* "Number of query heads must be divisible by ..."    (attention.jl:144) */
+    NNOP_ERR_DTYPE          = -5,  /* dtype not one of nnop_dtype (Julia: MethodError)                       */
+    NNOP_ERR_NULL           = -6,  /* a required pointer is NULL                                             */
+    NNOP_ERR_EMB_UNSUPPORTED= -7,  /* power of two but outside the kernels' range ("Failed to find groupsize
+                                      ... Shared Memory constraint", attention.jl:204)                       */
+    NNOP_ERR_SHAPE          = -8,  /* a non-positive / overflowing dimension                                 */
+    NNOP_ERR_WORKSPACE      = -9,  /* workspace smaller than nnop_fa_bwd_workspace_bytes                      */
+    NNOP_ERR_HIP            = -10  /* HIP runtime error at launch (hipGetLastError)                          */
+} nnop_status;
+
+/*
+ * Problem descriptor.  The reference reads all of this from the array sizes
+ * (src/attention.jl:138-139); across a C boundary the caller states it.
+ * `emb_k`, `kl_v`, `kh_v`, `emb_v` carry the K / V sizes that the reference's checks
+ * compare (E of K vs Q; size(k) == size(v)), so that those checks -- and their error
+ * codes -- live behind the boundary like they do in the reference.
+ */
+typedef struct nnop_fa_desc {
+    int32_t dtype;    /* nnop_dtype */
+    int32_t emb;      /* E  = size(q,1) */
+    int32_t ql;       /* QL = size(q,2) */
+    int32_t kl;       /* KL = size(k,2) */
+    int32_t qh;       /* QH = size(q,3) */
+    int32_t kh;       /* KH = size(k,3) */
+    int32_t batch;    /* B  = size(q,4) */
+    int32_t causal;   /* keyword `causal` (required in the reference, attention_crc.jl:7) */
+    int32_t emb_k;    /* size(k,1); 0 means "same as emb" */
+    int32_t emb_v;    /* size(v,1); 0 means "same as emb" */
+    int32_t kl_v;     /* size(v,2); 0 means "same as kl"  */
+    int32_t kh_v;     /* size(v,3); 0 means "same as kh"  */
+} nnop_fa_desc;
+
+/* Opaque to the ABI: a hipStream_t.  Declared void* so that C callers need no HIP headers. */
+typedef void* nnop_stream_t;
+
+/*
+ * Forward: contract of NNop._flash_attention (src/attention.jl:133-177) + kernel
+ * _flash_attention_fwd! (src/attention.jl:1-131).
+ *   o  = softmax(scale * q k^T (+pair) masked) v
+ *   ms = row max of the scaled+biased+masked logits   (src/attention.jl:128)
+ *   ls = sum_j exp(logit_j - ms)                       (src/attention.jl:129)
+ * `pair` and `kpad_mask` may be NULL (Julia `nothing`).
+ */
+int nnop_fa_fwd(const nnop_fa_desc* d,
+                void* o, void* ms, void* ls,
+                const void* q, const void* k, const void* v,
+                const void* pair, const uint8_t* kpad_mask,
+                nnop_stream_t stream);
+
+/*
+ * Scratch the backward needs (replaces the reference's internal Δ_scaled / δ temporaries,
+ * src/attention_bwd.jl:224-225).  Returns 0 for an invalid descriptor.
+ */
+size_t nnop_fa_bwd_workspace_bytes(const nnop_fa_desc* d);
+
+/*
+ * Backward: contract of NNop.∇flash_attention (src/attention_bwd.jl:199-275) + kernels
+ * _flash_attention_bwd_preprocess! (:163-197) and _flash_attention_bwd! (:1-161).
+ * Writes dq, dk, dv (fully overwritten -- the caller need not zero them) and, when `pair`
+ * is non-NULL, dpair (which must then be non-NULL too).  `d_o` is the cotangent Δ.
+ */
+int nnop_fa_bwd(const nnop_fa_desc* d,
+                void* dq, void* dk, void* dv, void* dpair,
+                const void* d_o, const void* o, const void* ms, const void* ls,
+                const void* q, const void* k, const void* v,
+                const void* pair, const uint8_t* kpad_mask,
+                void* workspace, size_t workspace_bytes,
+                nnop_stream_t stream);
+
+/* NNop._shared_memory(::ROCBackend, device_id) (ext/NNopAMDGPUExt.jl:6-9):
+ * hipDeviceProp_t.sharedMemPerBlock of `device` (0-based HIP ordinal). */
+int nnop_shared_memory(int device, uint64_t* bytes);
+
+/* Human-readable text for an nnop_status (static storage; never NULL). */
+const char* nnop_strerror(int status);
+
+/* ABI version of this header: bumped on any incompatible change. */
+#define NNOP_HIP_ABI_VERSION 1
+int nnop_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNOP_HIP_H */

@@ -1,0 +1,17 @@
+"""nnop.jl_amd -- MI355X-native Flash Attention behind NNop.jl's operator API.
+
+Holds only what the hot path needs: ``csrc/`` (hand-written gfx950 HIP kernels + the C ABI of
+``include/nnop_hip.h``), the host-side mirror of the reference interface (``attention.py``), the
+(batch, kv-head) sharding used for multi-GPU runs (``shard.py``) and the Julia package-extension
+shim (``julia/``, source only: no Julia in this image).
+
+The directory name contains a dot, so import it through ``__graft_entry__.load_package()``
+(registers it as module ``nnop_jl_amd``).
+"""
+from .attention import (NNopError, flash_attention, _flash_attention, grad_flash_attention,
+                        shared_memory, bwd_workspace_bytes)
+from . import _lib, shard
+
+__all__ = ["NNopError", "flash_attention", "_flash_attention", "grad_flash_attention",
+           "shared_memory", "bwd_workspace_bytes", "shard", "_lib"]
+__version__ = "0.1.0"

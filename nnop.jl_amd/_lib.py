@@ -1,0 +1,86 @@
+"""ctypes binding of libnnop_hip.so (the C ABI of include/nnop_hip.h).
+
+This is the same binding, call for call, that the Julia extension in ``julia/NNopHIPExt.jl``
+makes with ``ccall``.  There is NO fallback: if the shared library is missing or a symbol is
+absent the import of the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnnop_hip.so")
+
+# nnop_dtype (include/nnop_hip.h)
+NNOP_F32, NNOP_F16, NNOP_BF16 = 0, 1, 2
+
+# nnop_status (include/nnop_hip.h)
+NNOP_OK = 0
+NNOP_ERR_EMB_MISMATCH = -1
+NNOP_ERR_KV_SHAPE = -2
+NNOP_ERR_EMB_NOT_POW2 = -3
+NNOP_ERR_HEADS = -4
+NNOP_ERR_DTYPE = -5
+NNOP_ERR_NULL = -6
+NNOP_ERR_EMB_UNSUPPORTED = -7
+NNOP_ERR_SHAPE = -8
+NNOP_ERR_WORKSPACE = -9
+NNOP_ERR_HIP = -10
+
+EXPORTED_SYMBOLS = (
+    "nnop_fa_fwd",
+    "nnop_fa_bwd_workspace_bytes",
+    "nnop_fa_bwd",
+    "nnop_shared_memory",
+    "nnop_strerror",
+    "nnop_abi_version",
+)
+
+
+class FaDesc(C.Structure):
+    """struct nnop_fa_desc"""
+    _fields_ = [
+        ("dtype", C.c_int32), ("emb", C.c_int32), ("ql", C.c_int32), ("kl", C.c_int32),
+        ("qh", C.c_int32), ("kh", C.c_int32), ("batch", C.c_int32), ("causal", C.c_int32),
+        ("emb_k", C.c_int32), ("emb_v", C.c_int32), ("kl_v", C.c_int32), ("kh_v", C.c_int32),
+    ]
+
+
+class NNopLibraryMissing(ImportError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library once and declare the prototypes.  Raises loudly when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NNopLibraryMissing(
+            f"{LIB_PATH} not found: build it with `make -C nnop.jl_amd/csrc -j8` "
+            "(or __graft_entry__.build()).  There is no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u8p = C.c_void_p, C.c_void_p
+    lib.nnop_fa_fwd.restype = C.c_int
+    lib.nnop_fa_fwd.argtypes = [C.POINTER(FaDesc), vp, vp, vp, vp, vp, vp, vp, u8p, vp]
+    lib.nnop_fa_bwd_workspace_bytes.restype = C.c_size_t
+    lib.nnop_fa_bwd_workspace_bytes.argtypes = [C.POINTER(FaDesc)]
+    lib.nnop_fa_bwd.restype = C.c_int
+    lib.nnop_fa_bwd.argtypes = [C.POINTER(FaDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                u8p, vp, C.c_size_t, vp]
+    lib.nnop_shared_memory.restype = C.c_int
+    lib.nnop_shared_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+    lib.nnop_strerror.restype = C.c_char_p
+    lib.nnop_strerror.argtypes = [C.c_int]
+    lib.nnop_abi_version.restype = C.c_int
+    lib.nnop_abi_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def strerror(status: int) -> str:
+    return load().nnop_strerror(int(status)).decode()

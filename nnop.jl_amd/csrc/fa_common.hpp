@@ -1,0 +1,208 @@
+// fa_common.hpp -- device-side building blocks shared by the gfx950 flash-attention kernels.
+//
+// Everything here is written for CDNA4 (MI355X, gfx950) only: 64-lane wavefronts,
+// v_mfma_f32_32x32x16_{bf16,f16} / v_mfma_f32_32x32x2_f32, ds_read_b64_tr_b16,
+// v_permlane32_swap.  There is no other target and no fallback.
+//
+// Replaces (does not translate) the reference's LDS-tile scalar GEMM `mma!` and its
+// FATileConfig index conventions (src/mma.jl:1-48): the contraction runs on the matrix
+// cores with fp32 accumulation, and the tile "configs" become the two LDS image types below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nnop {
+
+typedef float    f32x16 __attribute__((ext_vector_type(16)));
+typedef float    f32x8  __attribute__((ext_vector_type(8)));
+typedef float    f32x4  __attribute__((ext_vector_type(4)));
+typedef float    f32x2  __attribute__((ext_vector_type(2)));
+typedef __bf16   bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16   bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16   bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8  __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4  __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2  __attribute__((ext_vector_type(2)));
+typedef short    s16x4  __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4  __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2  __attribute__((ext_vector_type(2)));
+
+#define NNOP_DEV __device__ __forceinline__
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2   = 0.6931471805599453f;
+
+// ----------------------------------------------------------------------------------------
+// Element traits.  A "fragment" is what ONE lane feeds to one 16-deep contraction step:
+// 8 elements.  For the 16-bit types that is exactly the A/B operand of
+// v_mfma_f32_32x32x16 (lane l = (r = l&31, h = l>>5) holds k = 8h + j, j = 0..7).  For fp32
+// the same 8 elements feed eight v_mfma_f32_32x32x2_f32 (lane holds k = h of each), i.e.
+// MFMA j contracts k in {j, 8 + j}: any k order is legal as long as A and B agree, so both
+// dtypes share one data layout.
+// ----------------------------------------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    using frag = f32x8;
+    static constexpr int kBytes = 4;
+};
+template <> struct Elem<_Float16> {
+    using frag = f16x8;
+    static constexpr int kBytes = 2;
+};
+template <> struct Elem<__bf16> {
+    using frag = bf16x8;
+    static constexpr int kBytes = 2;
+};
+
+template <typename T> NNOP_DEV f32x16 mma16(typename Elem<T>::frag a, typename Elem<T>::frag b, f32x16 c);
+template <> NNOP_DEV f32x16 mma16<__bf16>(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <> NNOP_DEV f32x16 mma16<_Float16>(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <> NNOP_DEV f32x16 mma16<float>(f32x8 a, f32x8 b, f32x16 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+
+// 8 consecutive accumulator registers (8s .. 8s+7) of a 32x32 result X as the fragment of
+// contraction step s of the NEXT product (the product then sums over X's ROW index; element
+// j of lane half h is X row 16s + 8(j>>2) + 4h + (j&3)).  No lane movement, no LDS.
+template <typename T, int S> NNOP_DEV typename Elem<T>::frag acc_frag(const f32x16& x) {
+    f32x8 t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = x[8 * S + j];
+    if constexpr (sizeof(T) == 4) {
+        return t;
+    } else {
+        return __builtin_convertvector(t, typename Elem<T>::frag);
+    }
+}
+
+// Row index (within a 32x32 MFMA result) held in accumulator register i by lane half h.
+NNOP_DEV constexpr int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+NNOP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// max over both 32-lane halves (lane l <-> l^32), result in every lane.
+NNOP_DEV float half_swap_max(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+NNOP_DEV float half_swap_sum(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <typename T> NNOP_DEV float to_f32(T x) { return (float)x; }
+template <typename T> NNOP_DEV T from_f32(float x) { return (T)x; }
+
+// ----------------------------------------------------------------------------------------
+// LDS images of a [ROWS][E] tile (ROWS = keys or queries, E = embedding, E fastest in HBM).
+//
+// RowImg: row-major, 16-byte chunks XOR-swizzled so that the MFMA "row read" -- lane (r,h)
+// takes 8 consecutive embedding elements of row r -- is bank-conflict free for ds_read_b128
+// (bank = (addr/4) % 64, serviced in 16-lane groups whose rows are distinct mod 16).
+//   chunk' = chunk ^ x(row),  x(row) = row & 15                      if row bytes >= 256
+//                             x(row) = (row / rows_per_256B) & (n16-1) otherwise
+// Whole rows are written from coalesced 16-byte global loads (8 consecutive lanes write a
+// permutation of one contiguous 128-byte span: conflict-free ds_write_b128).
+// ----------------------------------------------------------------------------------------
+template <typename T, int E> struct RowImg {
+    static constexpr int kRowBytes = E * (int)sizeof(T);
+    static constexpr int kN16      = kRowBytes / 16;            // 16-byte chunks per row
+    static_assert(kRowBytes >= 32, "row must hold one 16-deep contraction step");
+    static constexpr int bytes(int rows) { return rows * kRowBytes; }
+
+    NNOP_DEV static int xor_of(int row) {
+        if constexpr (kN16 >= 16) return row & 15;
+        else return (row / (16 / kN16)) & (kN16 - 1);
+    }
+    // byte offset of 16-byte chunk `c16` of row `row`
+    NNOP_DEV static int off(int row, int c16) { return row * kRowBytes + ((c16 ^ xor_of(row)) << 4); }
+
+    NNOP_DEV static void write16(char* img, int row, int c16, u32x4 v) {
+        *reinterpret_cast<u32x4*>(img + off(row, c16)) = v;
+    }
+    // fragment of contraction step ks (16 embedding elements) for this lane's row.
+    // `row` = tile row of this lane, h = lane >> 5.
+    NNOP_DEV static typename Elem<T>::frag read_row_frag(const char* img, int row, int h, int ks) {
+        if constexpr (sizeof(T) == 2) {
+            return *reinterpret_cast<const typename Elem<T>::frag*>(img + off(row, 2 * ks + h));
+        } else {
+            f32x4 a = *reinterpret_cast<const f32x4*>(img + off(row, 4 * ks + 2 * h));
+            f32x4 b = *reinterpret_cast<const f32x4*>(img + off(row, 4 * ks + 2 * h + 1));
+            f32x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            return r;
+        }
+    }
+};
+
+// ----------------------------------------------------------------------------------------
+// ColImg: image for the MFMA "column read" -- lane (r,h) takes, for embedding column
+// e = 32*eb + r, the 8 tile rows 16*kk + 8(j>>2) + 4h + (j&3), j = 0..7 (the row order an
+// accumulator tile has when it is the other operand, see acc_frag).
+//   16-bit: blocks of 4 rows x 32 columns stored contiguously (256 B = one LDS bank row):
+//           [row>>2][e>>5][row&3][e&31]; read with two ds_read_b64_tr_b16 (the hardware
+//           4x16 transpose), each 32-lane half covering exactly one 256-byte block.
+//           E = 16 is padded to 32 columns (upper 16 never stored, results discarded).
+//   fp32  : plain row-major; eight ds_read_b32, 32 lanes reading 128 contiguous bytes.
+// ----------------------------------------------------------------------------------------
+template <typename T, int E> struct ColImg {
+    static constexpr int kEP  = (sizeof(T) == 2 && E < 32) ? 32 : E;     // padded columns
+    static constexpr int kEB  = kEP / 32;                                  // 32-column blocks
+    static constexpr int kRowBytes = kEP * (int)sizeof(T);
+    static constexpr int bytes(int rows) { return rows * kRowBytes; }
+
+    NNOP_DEV static int off16(int row, int c16) {   // 16-bit: chunk c16 = 8 columns
+        return (((row >> 2) * kEB + (c16 >> 2)) << 8) + ((row & 3) << 6) + ((c16 & 3) << 4);
+    }
+    NNOP_DEV static void write16(char* img, int row, int c16, u32x4 v) {
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<u32x4*>(img + off16(row, c16)) = v;
+        else *reinterpret_cast<u32x4*>(img + row * kRowBytes + (c16 << 4)) = v;
+    }
+    // per-lane constant part of the column-read address (compute once per kernel)
+    NNOP_DEV static int lane_base(int lane) {
+        if constexpr (sizeof(T) == 2) {
+            const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+            return h * kEB * 256 + q * 64 + g1 * 32 + p * 8;
+        } else {
+            const int h = lane >> 5, r = lane & 31;
+            return 4 * h * kRowBytes + r * 4;
+        }
+    }
+    // fragment for 16-row step kk, column block eb.  base = img + lane_base(lane).
+    NNOP_DEV static typename Elem<T>::frag read_col_frag(const char* base, int kk, int eb) {
+        if constexpr (sizeof(T) == 2) {
+            typedef __attribute__((address_space(3))) s16x4* lds_p;
+            const char* p0 = base + (((4 * kk) * kEB + eb) << 8);
+            const char* p1 = base + (((4 * kk + 2) * kEB + eb) << 8);
+            s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+            s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            return __builtin_bit_cast(typename Elem<T>::frag, r);
+        } else {
+            f32x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = 16 * kk + 8 * (j >> 2) + (j & 3);
+                r[j] = *reinterpret_cast<const float*>(base + row * kRowBytes + eb * 128);
+            }
+            return r;
+        }
+    }
+};
+
+// XCD-aware, bijective remap of a linear workgroup id: workgroups b and b+8 share an XCD
+// (observed round-robin dispatch; a speed assumption only, never correctness), so give each
+// XCD one contiguous span of the logical tile order -> neighbouring tiles (same K/V) share
+// an L2.
+NNOP_DEV int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+}  // namespace nnop

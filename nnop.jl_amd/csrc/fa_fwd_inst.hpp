@@ -1,0 +1,66 @@
+// fa_fwd_inst.hpp -- host-side dispatch for the forward kernel; included by the three per-dtype
+// translation units so that they compile in parallel.
+//
+// Replaces the reference's host launcher heuristics (src/attention.jl:146-163, :193-218): there the
+// workgroup size is the largest of (256..16) whose backward LDS footprint fits; here the tile is
+// fixed by the MFMA shape (32 queries per wave, BK keys per step) and only the number of waves per
+// workgroup is chosen, from how many workgroups the problem yields against the chip's 256 CUs.
+#pragma once
+#include "fa_fwd.hpp"
+#include "fa_launch.hpp"
+#include <math.h>
+
+namespace nnop {
+
+template <typename T, int E, int NW, bool kGeneral>
+static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+    constexpr int BK = 64;
+    constexpr int lds = fa_fwd_lds_bytes<T, E, BK>();
+    static_assert(lds <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
+    auto kern = fa_fwd_kernel<T, E, NW, BK, kGeneral>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return NNOP_ERR_HIP;
+        }
+    }
+    FwdParams p;
+    p.o = a.o; p.ms = a.ms; p.ls = a.ls;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.pair = a.pair; p.kpad = a.kpad;
+    p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
+    p.causal = d.causal ? 1 : 0;
+    p.n_qblk = (d.ql + 32 * NW - 1) / (32 * NW);
+    const long long n_wg = (long long)p.n_qblk * d.qh * d.batch;
+    if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    p.n_wg = (int)n_wg;
+    p.scale = (float)(1.0 / sqrt((double)E));        // T(inv(sqrt(QE))), src/attention.jl:154
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, s, p);
+    return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
+}
+
+template <typename T, int E>
+static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+    const bool general = d.causal || a.kpad || a.pair || (d.kl % 64) != 0;
+    // waves per workgroup: 8 (256 query rows) when that still yields >= one workgroup per CU,
+    // else 4 (128 rows) so that small problems spread over more CUs.
+    int nw = 8;
+    const long long wg8 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
+    if (wg8 < 256 || d.ql <= 128) nw = 4;
+    nw = env_int("NNOP_FWD_NW", nw);
+    if (nw == 8) {
+        return general ? launch_fwd_cfg<T, E, 8, true>(d, a, s) : launch_fwd_cfg<T, E, 8, false>(d, a, s);
+    }
+    return general ? launch_fwd_cfg<T, E, 4, true>(d, a, s) : launch_fwd_cfg<T, E, 4, false>(d, a, s);
+}
+
+template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+    switch (d.emb) {
+        case 16:  return launch_fwd_e<T, 16>(d, a, s);
+        case 32:  return launch_fwd_e<T, 32>(d, a, s);
+        case 64:  return launch_fwd_e<T, 64>(d, a, s);
+        case 128: return launch_fwd_e<T, 128>(d, a, s);
+        default:  return NNOP_ERR_EMB_UNSUPPORTED;
+    }
+}
+
+}  // namespace nnop

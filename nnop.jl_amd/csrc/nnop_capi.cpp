@@ -1,0 +1,112 @@
+// nnop_capi.cpp -- the extern "C" boundary declared in include/nnop_hip.h.
+//
+// Mirrors the host side of the reference operator: the four argument checks of
+// `_flash_attention` / `∇flash_attention` (src/attention.jl:141-144, src/attention_bwd.jl:210-213)
+// become status codes; allocation of outputs and scratch moves to the caller; the launch is
+// asynchronous on the caller's stream (src/attention.jl:170-176 never synchronises either).
+#include "fa_launch.hpp"
+#include <stdlib.h>
+
+namespace nnop {
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    if (!s || !*s) return dflt;
+    return atoi(s);
+}
+
+static int check_desc(const nnop_fa_desc* d) {
+    if (!d) return NNOP_ERR_NULL;
+    if (d->dtype != NNOP_F32 && d->dtype != NNOP_F16 && d->dtype != NNOP_BF16) return NNOP_ERR_DTYPE;
+    if (d->emb <= 0 || d->ql <= 0 || d->kl <= 0 || d->qh <= 0 || d->kh <= 0 || d->batch <= 0) return NNOP_ERR_SHAPE;
+    const int emb_k = d->emb_k ? d->emb_k : d->emb;
+    const int emb_v = d->emb_v ? d->emb_v : emb_k;
+    const int kl_v  = d->kl_v ? d->kl_v : d->kl;
+    const int kh_v  = d->kh_v ? d->kh_v : d->kh;
+    // order of the reference's checks, src/attention.jl:141-144
+    if (d->emb != emb_k) return NNOP_ERR_EMB_MISMATCH;
+    if (emb_v != emb_k || kl_v != d->kl || kh_v != d->kh) return NNOP_ERR_KV_SHAPE;
+    if ((d->emb & (d->emb - 1)) != 0) return NNOP_ERR_EMB_NOT_POW2;
+    if (d->qh % d->kh != 0) return NNOP_ERR_HEADS;
+    if (!emb_supported(d->emb)) return NNOP_ERR_EMB_UNSUPPORTED;
+    // index arithmetic inside the kernels is 32-bit per (batch, head) slice
+    if ((long long)d->ql * d->emb > 0x7fffffffLL || (long long)d->kl * d->emb > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    return NNOP_OK;
+}
+}  // namespace nnop
+
+using namespace nnop;
+
+extern "C" {
+
+int nnop_abi_version(void) { return NNOP_HIP_ABI_VERSION; }
+
+const char* nnop_strerror(int status) {
+    switch (status) {
+        case NNOP_OK: return "success";
+        case NNOP_ERR_EMB_MISMATCH: return "Embedding dim of Q must be the same as of K.";
+        case NNOP_ERR_KV_SHAPE: return "Shapes of K and V must be the same.";
+        case NNOP_ERR_EMB_NOT_POW2: return "Only power-of-2 embedding dims are supported.";
+        case NNOP_ERR_HEADS: return "Number of query heads must be divisible by number of KV heads.";
+        case NNOP_ERR_DTYPE: return "Unsupported element type (expected Float32, Float16 or BFloat16).";
+        case NNOP_ERR_NULL: return "A required pointer argument is NULL.";
+        case NNOP_ERR_EMB_UNSUPPORTED:
+            return "Failed to find a Flash Attention tile configuration for this embedding dim (supported: 16, 32, 64, 128).";
+        case NNOP_ERR_SHAPE: return "A dimension is non-positive or too large.";
+        case NNOP_ERR_WORKSPACE: return "Backward workspace is smaller than nnop_fa_bwd_workspace_bytes().";
+        case NNOP_ERR_HIP: return "HIP runtime error at kernel launch.";
+        default: return "unknown nnop status";
+    }
+}
+
+int nnop_shared_memory(int device, uint64_t* bytes) {
+    if (!bytes) return NNOP_ERR_NULL;
+    int v = 0;
+    // hipDeviceProp_t.sharedMemPerBlock, as ext/NNopAMDGPUExt.jl:6-9 reads it
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return NNOP_ERR_HIP;
+    }
+    *bytes = (uint64_t)v;
+    return NNOP_OK;
+}
+
+int nnop_fa_fwd(const nnop_fa_desc* d, void* o, void* ms, void* ls, const void* q, const void* k,
+                const void* v, const void* pair, const uint8_t* kpad_mask, nnop_stream_t stream) {
+    const int st = check_desc(d);
+    if (st != NNOP_OK) return st;
+    if (!o || !ms || !ls || !q || !k || !v) return NNOP_ERR_NULL;
+    FwdArgs a{o, ms, ls, q, k, v, pair, kpad_mask};
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->dtype) {
+        case NNOP_F32:  return launch_fwd<float>(*d, a, s);
+        case NNOP_F16:  return launch_fwd<_Float16>(*d, a, s);
+        case NNOP_BF16: return launch_fwd<__bf16>(*d, a, s);
+    }
+    return NNOP_ERR_DTYPE;
+}
+
+size_t nnop_fa_bwd_workspace_bytes(const nnop_fa_desc* d) {
+    if (check_desc(d) != NNOP_OK) return 0;
+    return bwd_workspace_bytes(*d);
+}
+
+int nnop_fa_bwd(const nnop_fa_desc* d, void* dq, void* dk, void* dv, void* dpair, const void* d_o,
+                const void* o, const void* ms, const void* ls, const void* q, const void* k,
+                const void* v, const void* pair, const uint8_t* kpad_mask, void* workspace,
+                size_t workspace_bytes, nnop_stream_t stream) {
+    const int st = check_desc(d);
+    if (st != NNOP_OK) return st;
+    if (!dq || !dk || !dv || !d_o || !o || !ms || !ls || !q || !k || !v || !workspace) return NNOP_ERR_NULL;
+    if (pair && !dpair) return NNOP_ERR_NULL;
+    if (workspace_bytes < bwd_workspace_bytes(*d)) return NNOP_ERR_WORKSPACE;
+    BwdArgs a{dq, dk, dv, dpair, d_o, o, ms, ls, q, k, v, pair, kpad_mask, workspace};
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->dtype) {
+        case NNOP_F32:  return launch_bwd<float>(*d, a, s);
+        case NNOP_F16:  return launch_bwd<_Float16>(*d, a, s);
+        case NNOP_BF16: return launch_bwd<__bf16>(*d, a, s);
+    }
+    return NNOP_ERR_DTYPE;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import numpy as np
+import torch
+
+from oracle.naive_attention import naive_attention, naive_attention_grads
+
+TORCH_DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+# Tolerances stated by BASELINE.json north_star: fp32 rtol <= 1e-4, fp16/bf16 rtol <= 1e-2,
+# element-wise against the fp64 oracle evaluated on the ROUNDED inputs; atol is scaled to the
+# tensor's max magnitude.
+RTOL = {"f32": 1e-4, "f16": 1e-2, "bf16": 1e-2}
+ATOL_FRAC = {"f32": 1e-5, "f16": 2e-3, "bf16": 1e-2}
+
+
+def make_inputs(seed, B, QH, KH, QL, KL, E, dt, dev, *, pair=False, pad=None, need_do=True):
+    """N(0,1) inputs generated in fp32 with numpy default_rng(seed), cast to the test dtype."""
+    rng = np.random.default_rng(seed)
+    tdt = TORCH_DT[dt]
+    mk = lambda *s: torch.tensor(rng.standard_normal(s).astype(np.float32)).to(tdt).to(dev)
+    d = dict(q=mk(B, QH, QL, E), k=mk(B, KH, KL, E), v=mk(B, KH, KL, E))
+    d["do"] = mk(B, QH, QL, E) if need_do else None
+    d["pair"] = mk(B, KL, QL, QH) if pair else None
+    d["mask"] = None
+    if pad is not None:
+        m = np.ones((B, KL), dtype=bool)
+        if pad == "ref":                    # test/attention_tests.jl:27-28: last 11 keys of last batch
+            m[-1, -11:] = False
+        elif pad == "lens":                 # variable sequence lengths (prefix masks)
+            lens = rng.integers(1, KL + 1, size=B)
+            m = np.arange(KL)[None, :] < lens[:, None]
+        elif pad == "random":
+            m = rng.random((B, KL)) < 0.7
+            m[:, 0] = True
+        d["mask"] = torch.tensor(m).to(dev)
+    return d
+
+
+def to64(t):
+    return None if t is None else t.detach().to(torch.float64).cpu().numpy()
+
+
+def oracle_fwd(d, causal):
+    mask = None if d["mask"] is None else d["mask"].cpu().numpy()
+    return naive_attention(to64(d["q"]), to64(d["k"]), to64(d["v"]), to64(d["pair"]), causal=causal,
+                           kpad_mask=mask, return_stats=True)
+
+
+def oracle_bwd(d, causal):
+    mask = None if d["mask"] is None else d["mask"].cpu().numpy()
+    return naive_attention_grads(to64(d["q"]), to64(d["k"]), to64(d["v"]), to64(d["do"]), to64(d["pair"]),
+                                 causal=causal, kpad_mask=mask)
+
+
+def assert_close(name, got, ref, dt, scale=1.0):
+    """|got - ref| <= atol + rtol*|ref| element-wise, atol = ATOL_FRAC * max|ref|; plus the
+    reference's own norm-wise check (isapprox atol=rtol=1e-3, test/attention_tests.jl:42-48) for f32."""
+    g = to64(got) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    assert g.shape == ref.shape, f"{name}: shape {g.shape} vs {ref.shape}"
+    both_nan = np.isnan(g) & np.isnan(ref)
+    assert (np.isnan(g) == np.isnan(ref)).all(), f"{name}: NaN pattern differs"
+    gz, rz = np.where(both_nan, 0.0, g), np.where(both_nan, 0.0, ref)
+    mag = np.abs(rz).max() if rz.size else 0.0
+    tol = scale * (ATOL_FRAC[dt] * mag + RTOL[dt] * np.abs(rz))
+    err = np.abs(gz - rz)
+    bad = err > tol
+    assert not bad.any(), (f"{name} [{dt}]: {bad.sum()} / {bad.size} outside tolerance; "
+                           f"max err {err.max():.3e} (max|ref| {mag:.3e})")
+    if dt == "f32":
+        nrm = np.linalg.norm(gz - rz)
+        assert nrm <= max(1e-3, 1e-3 * max(np.linalg.norm(gz), np.linalg.norm(rz))), f"{name}: norm-wise 1e-3"
+    return float(err.max() / max(mag, 1e-30))
