@@ -1,0 +1,529 @@
+// fa_bwd.hpp -- gfx950 flash-attention backward kernels (templates; instantiated per dtype in
+// fa_bwd_*.hip).
+//
+// Computes what `∇flash_attention` computes (src/attention_bwd.jl:199-275) from the residuals
+// (o, ms, ls) of the forward:
+//     P  = exp(S - ms) / ls            S = scale*Q K^T (+pair), masked
+//     dV = P^T dO                      dP = dO V^T          delta = rowsum(dO o)
+//     dS = P o (dP - delta)            dpair = dS
+//     dQ = scale dS K                  dK = scale dS^T Q
+// (the reference folds 1/ls into dO -- "Δ_scaled", :183-188 -- and scale into dS, :118; same math).
+//
+// It is a different program from `_flash_attention_bwd!` (src/attention_bwd.jl:1-161):
+//
+//   reference                                        here
+//   ---------------------------------------------    -------------------------------------------
+//   ONE workgroup per (q-head, batch) walks all       two kernels, each with >= 256 workgroups:
+//   kv-tile x q-tile pairs (<= QH*B CUs busy)           dkdv: workgroup = key block of a (batch,
+//   dq/dk/dv read-modify-written in HBM every                 kv-head); dK^T, dV^T stay in MFMA
+//   inner iteration; KA.@atomic for GQA (:99-103)             accumulators across the sweep over the
+//   5 scalar-FMA LDS GEMMs + 9 barriers per pair              group's q-heads x q-tiles: no atomics,
+//   Q, K rounded to Float16 even for fp32 (:19-20)            GQA included, deterministic
+//   Δ_scaled materialised in HBM (:224)                 dq  : workgroup = query block; dQ^T in
+//                                                             accumulators across the key sweep
+//                                                     all five products on MFMA, fp32 accumulate,
+//                                                     operands in the input dtype (no Float16 detour)
+//                                                     1/ls and ms folded into ONE fp32 row constant
+//                                                     that is the INITIAL ACCUMULATOR of S (so
+//                                                     P = exp2(c*S') needs no subtraction), -delta
+//                                                     the initial accumulator of dP
+//
+// S and dP are recomputed in both kernels (7 products instead of 5): the price of having no
+// cross-workgroup dQ reduction (f32 atomics would bound the pass at ~1.3 TB/s of added bytes).
+#pragma once
+#include "fa_common.hpp"
+
+namespace nnop {
+
+struct BwdParams {
+    void *dq, *dk, *dv, *dpair;
+    const void *d_o, *o, *ms, *ls, *q, *k, *v, *pair;
+    const uint8_t* kpad;
+    float* nl;       // [B][QH][QL]  -(ms*log2e + log2(ls)) / (scale*log2e);  -inf for dead rows
+    float* delta;    // [B][QH][QL]  sum_e dO*o
+    int   QL, KL, QH, KH, B, causal;
+    int   n_blk;     // blocks along the workgroup's sequence axis
+    int   n_wg;
+    float scale;
+};
+
+// -------------------------------------------------------------------------------------------------
+// Preprocess (replaces _flash_attention_bwd_preprocess!, src/attention_bwd.jl:163-197).
+// HBM-streaming: reads dO and o once (16 bytes per lane), writes two fp32 per query row.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int E>
+__global__ __launch_bounds__(256) void fa_bwd_pre_kernel(const BwdParams p, long long n_rows) {
+    constexpr int LPR = E / 8;                       // lanes per row, 8 elements per lane
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = gid / LPR;
+    const int sub = (int)(gid % LPR);
+    float acc = 0.f;
+    if (row < n_rows) {
+        typedef T t8 __attribute__((ext_vector_type(8)));
+        const t8 a = *reinterpret_cast<const t8*>((const T*)p.d_o + row * E + sub * 8);
+        const t8 b = *reinterpret_cast<const t8*>((const T*)p.o + row * E + sub * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += to_f32(a[j]) * to_f32(b[j]);
+    }
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if (row < n_rows && sub == 0) {
+        const float m = to_f32(((const T*)p.ms)[row]);
+        const float l = to_f32(((const T*)p.ls)[row]);
+        const float c2 = p.scale * kLog2e;
+        float nl = -(m * kLog2e + __builtin_amdgcn_logf(l)) / c2;   // v_log_f32 = log2
+        float dl = acc;
+        if (!(l > 0.f) || !(nl == nl) || m == -INFINITY) {           // row with no visible key
+            nl = -INFINITY;
+            dl = 0.f;
+        }
+        p.nl[row] = nl;
+        p.delta[row] = dl;
+    }
+}
+
+// store a transposed accumulator (rows = embedding in registers, column = this lane's sequence row)
+template <typename T, int E>
+NNOP_DEV void store_acc_row(T* rowp, const f32x16* acc, float mul, int h) {
+    constexpr int EB = (E + 31) / 32;
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int e = 32 * eb + 8 * g + 4 * h;
+            if (e < E) {
+                f32x4 w = {acc[eb][4 * g] * mul, acc[eb][4 * g + 1] * mul, acc[eb][4 * g + 2] * mul,
+                           acc[eb][4 * g + 3] * mul};
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<f32x4*>(rowp + e) = w;
+                } else {
+                    typedef T t4 __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<t4*>(rowp + e) = __builtin_convertvector(w, t4);
+                }
+            }
+        }
+}
+
+template <typename T, int E> struct BwdImgs {
+    using Row = RowImg<T, E>;
+    using Col = ColImg<T, E>;
+    // a tile that is read both by rows and by columns: fp32 uses ONE swizzled image, the 16-bit
+    // types a row image + a transposed-read image.
+    static constexpr bool kDual = sizeof(T) == 4;
+    static constexpr int both(int rows) { return kDual ? Row::bytes(rows) : Row::bytes(rows) + Col::bytes(rows); }
+};
+
+// -------------------------------------------------------------------------------------------------
+// dK, dV.  Workgroup = 32*NW keys of one (batch, kv-head); each wave owns 32 keys (key on the lane)
+// and keeps dK^T[e][key], dV^T[e][key] in accumulators while the workgroup sweeps the group's
+// q-heads x q-tiles of BQ queries (double-buffered Q / dO images, one barrier per q-tile).
+//   S  [q][key] = Q K^T   : A = Q rows (LDS),  B = K (registers / LDS)
+//   dP [q][key] = dO V^T  : A = dO rows (LDS), B = V
+//   dV^T += dO^T P        : A = dO columns (LDS transposed read), B = P  straight from accumulators
+//   dK^T += Q^T dS        : A = Q columns,                        B = dS straight from accumulators
+// -------------------------------------------------------------------------------------------------
+template <typename T, int E, int NW, int BQ>
+constexpr int fa_bwd_dkdv_lds_bytes() {
+    constexpr bool kv_regs = sizeof(T) == 2 || E <= 64;
+    return (kv_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) + 2 * (2 * BwdImgs<T, E>::both(BQ) + 2 * BQ * 4);
+}
+
+template <typename T, int E, int NW, int BQ, bool kGeneral>
+__global__ __launch_bounds__(NW * 64) void fa_bwd_dkdv_kernel(const BwdParams p) {
+    using frag_t = typename Elem<T>::frag;
+    using Imgs = BwdImgs<T, E>;
+    using Row = typename Imgs::Row;
+    using Col = typename Imgs::Col;
+    constexpr int NT = NW * 64;
+    constexpr int KS = E / 16;
+    constexpr int EB = (E + 31) / 32;
+    constexpr int QB = BQ / 32;
+    constexpr bool kKVRegs = sizeof(T) == 2 || E <= 64;
+    constexpr int KVIMG = kKVRegs ? 0 : Row::bytes(32 * NW);
+    constexpr int QIMG = Imgs::both(BQ);
+    constexpr int BUF = 2 * QIMG + 2 * BQ * 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    const int lin  = xcd_remap((int)blockIdx.x, p.n_wg);
+    const int kblk = lin % p.n_blk;
+    const int bk   = lin / p.n_blk;
+    const int b    = bk / p.KH;
+    const int kvh  = bk - b * p.KH;
+    const int rep  = p.QH / p.KH;
+    const int k0wg = kblk * (32 * NW);
+    const int kw0  = k0wg + wave * 32;
+    const int key  = kw0 + r;
+    const int key_c = key < p.KL ? key : p.KL - 1;
+    const float c2 = p.scale * kLog2e;
+
+    const T* __restrict__ kp = (const T*)p.k + ((size_t)(b * p.KH + kvh) * p.KL) * E;
+    const T* __restrict__ vp = (const T*)p.v + ((size_t)(b * p.KH + kvh) * p.KL) * E;
+
+    bool kvalid = key < p.KL;
+    if (kGeneral && p.kpad && kvalid) kvalid = p.kpad[(size_t)b * p.KL + key] != 0;
+
+    // ---- K, V fragments (B operands: k = embedding, column = key on the lane) ------------------
+    frag_t kf[kKVRegs ? KS : 1], vf[kKVRegs ? KS : 1];
+    char* kimg = smem;
+    char* vimg = smem + KVIMG;
+    char* bufs = smem + 2 * KVIMG;
+    if constexpr (kKVRegs) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = *reinterpret_cast<const frag_t*>(kp + (size_t)key_c * E + 16 * ks + 8 * h);
+            vf[ks] = *reinterpret_cast<const frag_t*>(vp + (size_t)key_c * E + 16 * ks + 8 * h);
+        }
+    } else {
+        Stager<T, E, 32 * NW, NT> sk, sv;
+        sk.load(kp + (size_t)k0wg * E, p.KL - k0wg, tid);
+        sv.load(vp + (size_t)k0wg * E, p.KL - k0wg, tid);
+        sk.template write<Row>(kimg, tid);
+        sv.template write<Row>(vimg, tid);
+    }
+
+    // ---- iteration space: (q-head of the group) x (q-tile) --------------------------------------
+    const int n_qt = (p.QL + BQ - 1) / BQ;
+    int qt0 = 0;
+    if (kGeneral && p.causal) qt0 = k0wg / BQ;           // queries < first key of the block see none of it
+    const int nqt = n_qt > qt0 ? n_qt - qt0 : 0;
+    const int n_it = nqt * rep;
+
+    Stager<T, E, BQ, NT> sq, sdo;
+    float rowc = 0.f;                                     // nl (tid < BQ) or delta (BQ <= tid < 2BQ)
+    auto stage_load = [&](int it) {
+        const int g = it / nqt, qt = qt0 + it - g * nqt;
+        const int qh = kvh * rep + g;
+        const size_t row0 = (size_t)(b * p.QH + qh) * p.QL + (size_t)qt * BQ;
+        sq.load((const T*)p.q + row0 * E, p.QL - qt * BQ, tid);
+        sdo.load((const T*)p.d_o + row0 * E, p.QL - qt * BQ, tid);
+        if (tid < 2 * BQ) {
+            const int rr = tid < BQ ? tid : tid - BQ;
+            const bool in = qt * BQ + rr < p.QL;
+            if (tid < BQ) rowc = in ? p.nl[row0 + rr] : -INFINITY;
+            else rowc = in ? -p.delta[row0 + rr] : 0.f;
+        }
+    };
+    auto stage_write = [&](char* buf) {
+        sq.template write<Row>(buf, tid);
+        sdo.template write<Row>(buf + QIMG, tid);
+        if constexpr (!Imgs::kDual) {
+            sq.template write<Col>(buf + Row::bytes(BQ), tid);
+            sdo.template write<Col>(buf + QIMG + Row::bytes(BQ), tid);
+        }
+        if (tid < 2 * BQ) reinterpret_cast<float*>(buf + 2 * QIMG)[tid] = rowc;
+    };
+
+    f32x16 dka[EB], dva[EB];
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dka[eb][i] = 0.f; dva[eb][i] = 0.f; }
+
+    const int cbase = Col::lane_base(lane);
+
+    if (n_it > 0) {
+        stage_load(0);
+        stage_write(bufs);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < n_it; ++it) {
+        char* cur = bufs + (it & 1) * BUF;
+        char* nxt = bufs + ((it + 1) & 1) * BUF;
+        const bool more = it + 1 < n_it;
+        if (more) stage_load(it + 1);
+
+        const int g = it / nqt, qt = qt0 + it - g * nqt;
+        const int qh = kvh * rep + g;
+        const char* qrow = cur;
+        const char* dorow = cur + QIMG;
+        const char* qcol = cur + Row::bytes(BQ) + cbase;
+        const char* docol = cur + QIMG + Row::bytes(BQ) + cbase;
+        const float* rc = reinterpret_cast<const float*>(cur + 2 * QIMG);
+
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int q0 = qt * BQ + 32 * qb;
+            if (q0 >= p.QL) continue;
+            if (kGeneral && p.causal && q0 + 31 < kw0) continue;       // block entirely above the diagonal
+
+            f32x16 s, dp;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(rc + 32 * qb + 8 * g4 + 4 * h);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(rc + BQ + 32 * qb + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[4 * g4 + j] = a[j]; dp[4 * g4 + j] = d[j]; }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                frag_t kfr, vfr;
+                if constexpr (kKVRegs) { kfr = kf[ks]; vfr = vf[ks]; }
+                else {
+                    kfr = Row::read_row_frag(kimg, 32 * wave + r, h, ks);
+                    vfr = Row::read_row_frag(vimg, 32 * wave + r, h, ks);
+                }
+                s  = mma16<T>(Row::read_row_frag(qrow, 32 * qb + r, h, ks), kfr, s);
+                dp = mma16<T>(Row::read_row_frag(dorow, 32 * qb + r, h, ks), vfr, dp);
+            }
+
+            // P = exp2(c*S'), dS = P*dP'   (rows = queries in registers, key on the lane)
+            const bool diag = kGeneral && p.causal && (q0 < kw0 + 31);
+            f32x16 ds;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float x = s[i] * c2;
+                const int qrow_i = q0 + acc_row(i, h);
+                bool ok = true;
+                if constexpr (kGeneral) {
+                    ok = kvalid;
+                    if (diag) ok = ok && (qrow_i >= key);
+                    if (p.pair && ok && qrow_i < p.QL) {
+                        const size_t po = (((size_t)b * p.KL + key) * p.QL + qrow_i) * p.QH + qh;
+                        x += to_f32(((const T*)p.pair)[po]) * kLog2e;
+                    }
+                }
+                float pr = fast_exp2(x);
+                if constexpr (kGeneral) pr = ok ? pr : 0.f;
+                s[i] = pr;
+                ds[i] = pr * dp[i];
+                if constexpr (kGeneral) {
+                    if (p.dpair && key < p.KL && qrow_i < p.QL) {
+                        const size_t po = (((size_t)b * p.KL + key) * p.QL + qrow_i) * p.QH + qh;
+                        ((T*)p.dpair)[po] = from_f32<T>(ds[i]);
+                    }
+                }
+            }
+            const frag_t p0 = acc_frag<T, 0>(s), p1 = acc_frag<T, 1>(s);
+            const frag_t d0 = acc_frag<T, 0>(ds), d1 = acc_frag<T, 1>(ds);
+#pragma unroll
+            for (int eb = 0; eb < EB; ++eb) {
+                frag_t a0, a1, b0, b1;
+                if constexpr (Imgs::kDual) {
+                    a0 = Row::read_col_frag_f32(dorow, r, h, 2 * qb, eb);
+                    a1 = Row::read_col_frag_f32(dorow, r, h, 2 * qb + 1, eb);
+                    b0 = Row::read_col_frag_f32(qrow, r, h, 2 * qb, eb);
+                    b1 = Row::read_col_frag_f32(qrow, r, h, 2 * qb + 1, eb);
+                } else {
+                    a0 = Col::read_col_frag(docol, 2 * qb, eb);
+                    a1 = Col::read_col_frag(docol, 2 * qb + 1, eb);
+                    b0 = Col::read_col_frag(qcol, 2 * qb, eb);
+                    b1 = Col::read_col_frag(qcol, 2 * qb + 1, eb);
+                }
+                dva[eb] = mma16<T>(a0, p0, dva[eb]);
+                dva[eb] = mma16<T>(a1, p1, dva[eb]);
+                dka[eb] = mma16<T>(b0, d0, dka[eb]);
+                dka[eb] = mma16<T>(b1, d1, dka[eb]);
+            }
+        }
+
+        if (more) stage_write(nxt);
+        __syncthreads();
+    }
+
+    if (key < p.KL) {
+        const size_t ro = ((size_t)(b * p.KH + kvh) * p.KL + key) * E;
+        store_acc_row<T, E>((T*)p.dk + ro, dka, p.scale, h);
+        store_acc_row<T, E>((T*)p.dv + ro, dva, 1.0f, h);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// dQ.  Workgroup = 32*NW queries of one (batch, q-head); each wave owns 32 queries (query on the
+// lane) and keeps dQ^T[e][query] in accumulators while the workgroup sweeps kv tiles of BK keys
+// (double-buffered, one barrier per tile) -- the forward's structure with
+//   S^T [key][q] = K Q^T   (init: nl[q])      dP^T [key][q] = V dO^T   (init: -delta[q])
+//   dQ^T += K^T dS^T : A = K columns (LDS transposed read), B = dS^T straight from accumulators
+// -------------------------------------------------------------------------------------------------
+template <typename T, int E, int NW, int BK>
+constexpr int fa_bwd_dq_lds_bytes() {
+    constexpr bool qdo_regs = sizeof(T) == 2 || E <= 64;
+    return (qdo_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) +
+           2 * (BwdImgs<T, E>::both(BK) + RowImg<T, E>::bytes(BK));
+}
+
+template <typename T, int E, int NW, int BK, bool kGeneral>
+__global__ __launch_bounds__(NW * 64) void fa_bwd_dq_kernel(const BwdParams p) {
+    using frag_t = typename Elem<T>::frag;
+    using Imgs = BwdImgs<T, E>;
+    using Row = typename Imgs::Row;
+    using Col = typename Imgs::Col;
+    constexpr int NT = NW * 64;
+    constexpr int KS = E / 16;
+    constexpr int EB = (E + 31) / 32;
+    constexpr int KB = BK / 32;
+    constexpr bool kQRegs = sizeof(T) == 2 || E <= 64;
+    constexpr int QIMG = kQRegs ? 0 : Row::bytes(32 * NW);
+    constexpr int KIMG = Imgs::both(BK);
+    constexpr int BUF = KIMG + Row::bytes(BK);
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    int lin = xcd_remap((int)blockIdx.x, p.n_wg);
+    int qblk = lin % p.n_blk;
+    const int bh = lin / p.n_blk;
+    if (p.causal) qblk = p.n_blk - 1 - qblk;
+    const int b = bh / p.QH;
+    const int qh = bh - b * p.QH;
+    const int kvh = qh / (p.QH / p.KH);
+    const int q0wg = qblk * (32 * NW);
+    const int q0w = q0wg + wave * 32;
+    const int qi = q0w + r;
+    const int qi_c = qi < p.QL ? qi : p.QL - 1;
+    const float c2 = p.scale * kLog2e;
+
+    const T* __restrict__ qp  = (const T*)p.q + ((size_t)bh * p.QL) * E;
+    const T* __restrict__ dop = (const T*)p.d_o + ((size_t)bh * p.QL) * E;
+    const T* __restrict__ kp = (const T*)p.k + ((size_t)(b * p.KH + kvh) * p.KL) * E;
+    const T* __restrict__ vp = (const T*)p.v + ((size_t)(b * p.KH + kvh) * p.KL) * E;
+    const uint8_t* __restrict__ mp = kGeneral && p.kpad ? p.kpad + (size_t)b * p.KL : nullptr;
+
+    int n_tiles = (p.KL + BK - 1) / BK;
+    if (kGeneral && p.causal) {
+        int q_last = q0wg + 32 * NW - 1;
+        if (q_last > p.QL - 1) q_last = p.QL - 1;
+        const int t_c = q_last / BK + 1;
+        if (t_c < n_tiles) n_tiles = t_c;
+    }
+
+    const float nlq = qi < p.QL ? p.nl[(size_t)bh * p.QL + qi] : -INFINITY;
+    const float ndl = qi < p.QL ? -p.delta[(size_t)bh * p.QL + qi] : 0.f;
+
+    frag_t qf[kQRegs ? KS : 1], dof[kQRegs ? KS : 1];
+    char* qimg = smem;
+    char* doimg = smem + QIMG;
+    char* bufs = smem + 2 * QIMG;
+    if constexpr (kQRegs) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks]  = *reinterpret_cast<const frag_t*>(qp + (size_t)qi_c * E + 16 * ks + 8 * h);
+            dof[ks] = *reinterpret_cast<const frag_t*>(dop + (size_t)qi_c * E + 16 * ks + 8 * h);
+        }
+    } else {
+        Stager<T, E, 32 * NW, NT> s1, s2;
+        s1.load(qp + (size_t)q0wg * E, p.QL - q0wg, tid);
+        s2.load(dop + (size_t)q0wg * E, p.QL - q0wg, tid);
+        s1.template write<Row>(qimg, tid);
+        s2.template write<Row>(doimg, tid);
+    }
+
+    Stager<T, E, BK, NT> sk, sv;
+    auto stage_load = [&](int t) {
+        sk.load(kp + (size_t)t * BK * E, p.KL - t * BK, tid);
+        sv.load(vp + (size_t)t * BK * E, p.KL - t * BK, tid);
+    };
+    auto stage_write = [&](char* buf) {
+        sk.template write<Row>(buf, tid);
+        if constexpr (!Imgs::kDual) sk.template write<Col>(buf + Row::bytes(BK), tid);
+        sv.template write<Row>(buf + KIMG, tid);
+    };
+
+    f32x16 dqa[EB];
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dqa[eb][i] = 0.f;
+    const int cbase = Col::lane_base(lane);
+
+    stage_load(0);
+    stage_write(bufs);
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+        char* cur = bufs + (t & 1) * BUF;
+        char* nxt = bufs + ((t + 1) & 1) * BUF;
+        const bool more = t + 1 < n_tiles;
+        if (more) stage_load(t + 1);
+
+        const int k0 = t * BK;
+        bool skip = false, need_mask = false;
+        uint64_t valid = ~0ull;
+        if constexpr (kGeneral) {
+            if (p.causal && k0 > q0w + 31) skip = true;
+            if (BK < 64) valid = (1ull << BK) - 1ull;
+            if (k0 + BK > p.KL) valid &= (p.KL - k0 >= 64) ? ~0ull : ((1ull << (p.KL - k0)) - 1ull);
+            if (mp) {
+                const int kk = k0 + lane;
+                const bool lv = (lane < BK && kk < p.KL) ? (mp[kk] != 0) : false;
+                valid &= __ballot(lv);
+            }
+            if (valid == 0ull) skip = true;
+            need_mask = (valid != ((BK < 64) ? ((1ull << BK) - 1ull) : ~0ull)) ||
+                        (p.causal && k0 + BK - 1 > q0w) || (p.pair != nullptr);
+        }
+
+        if (!skip) {
+            const char* krow = cur;
+            const char* kcol = cur + Row::bytes(BK) + cbase;
+            const char* vrow = cur + KIMG;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s[i] = nlq; dp[i] = ndl; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    frag_t qfr, dofr;
+                    if constexpr (kQRegs) { qfr = qf[ks]; dofr = dof[ks]; }
+                    else {
+                        qfr = Row::read_row_frag(qimg, 32 * wave + r, h, ks);
+                        dofr = Row::read_row_frag(doimg, 32 * wave + r, h, ks);
+                    }
+                    s  = mma16<T>(Row::read_row_frag(krow, 32 * kb + r, h, ks), qfr, s);
+                    dp = mma16<T>(Row::read_row_frag(vrow, 32 * kb + r, h, ks), dofr, dp);
+                }
+                const uint32_t w = (uint32_t)(valid >> (32 * kb + 4 * h));
+                const int lim = qi - k0 - 32 * kb - 4 * h;
+                f32x16 ds;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float x = s[i] * c2;
+                    bool ok = true;
+                    if constexpr (kGeneral) {
+                        if (need_mask) {
+                            const int lr = (i & 3) + 8 * (i >> 2);
+                            ok = (w >> lr) & 1u;
+                            if (p.causal) ok = ok && (lr <= lim);
+                            if (p.pair && ok && qi < p.QL) {
+                                const int kkey = k0 + 32 * kb + lr + 4 * h;
+                                const size_t po = (((size_t)b * p.KL + kkey) * p.QL + qi) * p.QH + qh;
+                                x += to_f32(((const T*)p.pair)[po]) * kLog2e;
+                            }
+                        }
+                    }
+                    float pr = fast_exp2(x);
+                    if constexpr (kGeneral) pr = ok ? pr : 0.f;
+                    ds[i] = pr * dp[i];
+                }
+                const frag_t d0 = acc_frag<T, 0>(ds), d1 = acc_frag<T, 1>(ds);
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb) {
+                    frag_t a0, a1;
+                    if constexpr (Imgs::kDual) {
+                        a0 = Row::read_col_frag_f32(krow, r, h, 2 * kb, eb);
+                        a1 = Row::read_col_frag_f32(krow, r, h, 2 * kb + 1, eb);
+                    } else {
+                        a0 = Col::read_col_frag(kcol, 2 * kb, eb);
+                        a1 = Col::read_col_frag(kcol, 2 * kb + 1, eb);
+                    }
+                    dqa[eb] = mma16<T>(a0, d0, dqa[eb]);
+                    dqa[eb] = mma16<T>(a1, d1, dqa[eb]);
+                }
+            }
+        }
+
+        if (more) stage_write(nxt);
+        __syncthreads();
+    }
+
+    if (qi < p.QL) store_acc_row<T, E>((T*)p.dq + ((size_t)bh * p.QL + qi) * E, dqa, p.scale, h);
+}
+
+}  // namespace nnop

@@ -1,0 +1,105 @@
+// fa_bwd_inst.hpp -- host-side dispatch for the backward kernels; included by the three per-dtype
+// translation units.  Replaces the reference's `∇flash_attention` host body
+// (src/attention_bwd.jl:215-272): three launches on the caller's stream (preprocess, dK/dV, dQ),
+// scratch from the caller's workspace, dpair zero-filled only when a pair bias is given.
+#pragma once
+#include "fa_bwd.hpp"
+#include "fa_launch.hpp"
+#include <math.h>
+
+namespace nnop {
+
+template <typename T, int E> struct BwdCfg {
+    static constexpr bool kF32 = sizeof(T) == 4;
+    // fp32 at E=128 keeps K,V (dkdv) / Q,dO (dq) in LDS instead of registers: fewer waves, smaller tiles
+    static constexpr int NW_KV = (kF32 && E > 64) ? 2 : 4;
+    static constexpr int BQ    = (kF32 || E > 64) ? 32 : 64;
+    static constexpr int NW_Q  = (kF32 && E > 64) ? 2 : 4;
+    static constexpr int BK    = (kF32 && E > 64) ? 32 : 64;
+};
+
+template <typename K> static int set_lds(K kern, int lds) {
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return NNOP_ERR_HIP;
+        }
+    }
+    return NNOP_OK;
+}
+
+template <typename T, int E, bool kGeneral>
+static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
+    using C = BwdCfg<T, E>;
+    BwdParams p;
+    p.dq = a.dq; p.dk = a.dk; p.dv = a.dv; p.dpair = a.pair ? a.dpair : nullptr;
+    p.d_o = a.d_o; p.o = a.o; p.ms = a.ms; p.ls = a.ls;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.pair = a.pair; p.kpad = a.kpad;
+    const long long n_rows = (long long)d.batch * d.qh * d.ql;
+    p.nl = (float*)a.workspace;
+    p.delta = p.nl + n_rows;
+    p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
+    p.causal = d.causal ? 1 : 0;
+    p.scale = (float)(1.0 / sqrt((double)E));
+    p.n_blk = 0; p.n_wg = 0;
+
+    // 1. preprocess
+    {
+        const long long n_thr = n_rows * (E / 8);
+        const long long grid = (n_thr + 255) / 256;
+        if (grid > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+        hipLaunchKernelGGL((fa_bwd_pre_kernel<T, E>), dim3((unsigned)grid), dim3(256), 0, s, p, n_rows);
+    }
+    // 2. dpair is written only where a (query, key) pair is visited: zero it first
+    if (p.dpair) {
+        const size_t bytes = (size_t)d.batch * d.kl * d.ql * d.qh * sizeof(T);
+        if (hipMemsetAsync(p.dpair, 0, bytes, s) != hipSuccess) { (void)hipGetLastError(); return NNOP_ERR_HIP; }
+    }
+    // 3. dK, dV
+    {
+        constexpr int NW = C::NW_KV, BQ = C::BQ;
+        constexpr int lds = fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>();
+        static_assert(lds <= 160 * 1024, "LDS budget");
+        auto kern = fa_bwd_dkdv_kernel<T, E, NW, BQ, kGeneral>;
+        if (set_lds(kern, lds) != NNOP_OK) return NNOP_ERR_HIP;
+        BwdParams pk = p;
+        pk.n_blk = (d.kl + 32 * NW - 1) / (32 * NW);
+        const long long n_wg = (long long)pk.n_blk * d.kh * d.batch;
+        if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+        pk.n_wg = (int)n_wg;
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, s, pk);
+    }
+    // 4. dQ
+    {
+        constexpr int NW = C::NW_Q, BK = C::BK;
+        constexpr int lds = fa_bwd_dq_lds_bytes<T, E, NW, BK>();
+        static_assert(lds <= 160 * 1024, "LDS budget");
+        auto kern = fa_bwd_dq_kernel<T, E, NW, BK, kGeneral>;
+        if (set_lds(kern, lds) != NNOP_OK) return NNOP_ERR_HIP;
+        BwdParams pq = p;
+        pq.n_blk = (d.ql + 32 * NW - 1) / (32 * NW);
+        const long long n_wg = (long long)pq.n_blk * d.qh * d.batch;
+        if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+        pq.n_wg = (int)n_wg;
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, s, pq);
+    }
+    return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
+}
+
+template <typename T, int E>
+static int launch_bwd_e(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
+    const bool general = d.causal || a.kpad || a.pair;
+    return general ? launch_bwd_cfg<T, E, true>(d, a, s) : launch_bwd_cfg<T, E, false>(d, a, s);
+}
+
+template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
+    switch (d.emb) {
+        case 16:  return launch_bwd_e<T, 16>(d, a, s);
+        case 32:  return launch_bwd_e<T, 32>(d, a, s);
+        case 64:  return launch_bwd_e<T, 64>(d, a, s);
+        case 128: return launch_bwd_e<T, 128>(d, a, s);
+        default:  return NNOP_ERR_EMB_UNSUPPORTED;
+    }
+}
+
+}  // namespace nnop

@@ -138,6 +138,20 @@ template <typename T, int E> struct RowImg {
             return r;
         }
     }
+    // fp32 only: the MFMA "column read" (see ColImg) served from THIS swizzled row-major image,
+    // so that a tile consumed both ways (backward: Q, dO, K) needs one LDS copy.  Lane (r,h)
+    // reads column 32*eb + r of rows 16*kk + 8(j>>2) + 4h + (j&3): 32 lanes touch a permutation
+    // of 128 contiguous bytes of one row -> conflict-free ds_read_b32.
+    NNOP_DEV static f32x8 read_col_frag_f32(const char* img, int r, int h, int kk, int eb) {
+        static_assert(sizeof(T) == 4 || E > 0, "");
+        f32x8 out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = 16 * kk + 8 * (j >> 2) + 4 * h + (j & 3);
+            out[j] = *reinterpret_cast<const float*>(img + off(row, (8 * eb + (r >> 2)) & (kN16 - 1)) + ((r & 3) << 2));
+        }
+        return out;
+    }
 };
 
 // ----------------------------------------------------------------------------------------
@@ -192,6 +206,38 @@ template <typename T, int E> struct ColImg {
                 r[j] = *reinterpret_cast<const float*>(base + row * kRowBytes + eb * 128);
             }
             return r;
+        }
+    }
+};
+
+// ----------------------------------------------------------------------------------------
+// Stager: the NT threads of a workgroup move a dense [ROWS][E] tile HBM -> registers (16-byte
+// coalesced loads, issued early) -> LDS images (written late, after the compute phase that
+// hides the load latency).  Rows >= rows_valid are zero-filled.
+// ----------------------------------------------------------------------------------------
+template <typename T, int E, int ROWS, int NT> struct Stager {
+    static constexpr int kN16 = E * (int)sizeof(T) / 16;
+    static constexpr int kNCH = ROWS * kN16;
+    static constexpr int kNLD = (kNCH + NT - 1) / NT;
+    u32x4 reg[kNLD];
+
+    // gtile: address of row 0 of the tile; rows_valid: rows that exist (may be <= 0 or >= ROWS)
+    NNOP_DEV void load(const void* gtile, int rows_valid, int tid) {
+#pragma unroll
+        for (int i = 0; i < kNLD; ++i) {
+            const int c = tid + i * NT;
+            const int row = c / kN16;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            reg[i] = z;
+            if ((kNCH % NT == 0 || c < kNCH) && row < rows_valid)
+                reg[i] = *reinterpret_cast<const u32x4*>((const char*)gtile + (size_t)c * 16);
+        }
+    }
+    template <typename Img> NNOP_DEV void write(char* img, int tid) const {
+#pragma unroll
+        for (int i = 0; i < kNLD; ++i) {
+            const int c = tid + i * NT;
+            if (kNCH % NT == 0 || c < kNCH) Img::write16(img, c / kN16, c % kN16, reg[i]);
         }
     }
 };

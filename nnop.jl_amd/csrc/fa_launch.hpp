@@ -28,9 +28,9 @@ template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hi
 // Embedding dims the MFMA kernels are instantiated for.
 inline bool emb_supported(int e) { return e == 16 || e == 32 || e == 64 || e == 128; }
 
-// bytes of backward scratch: delta[B][QH][QL] in fp32
+// bytes of backward scratch: two fp32 per query row (folded log-sum-exp, delta), [2][B][QH][QL]
 inline size_t bwd_workspace_bytes(const nnop_fa_desc& d) {
-    return (size_t)d.batch * d.qh * d.ql * sizeof(float);
+    return 2 * (size_t)d.batch * d.qh * d.ql * sizeof(float);
 }
 
 // Optional tuning override (read-only environment): workgroup waves for the forward.
