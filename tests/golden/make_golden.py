@@ -1,0 +1,76 @@
+"""Generates the golden fixtures in this directory from the fp64 oracle.
+
+    python tests/golden/make_golden.py
+
+The reference (Julia, GPU-only kernels, no golden vectors of its own -- SURVEY.md section 8(c))
+cannot produce vectors here, so these fixtures freeze the ORACLE: inputs are N(0,1) from
+numpy.random.default_rng(seed), rounded to bf16-representable fp32 values (so the same fixture
+is exact input for the f32, f16 and bf16 paths), expected outputs are the fp64 oracle's, stored
+as fp32.  A fixture is data only: inputs and expected outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.naive_attention import naive_attention, naive_attention_grads  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name: (seed, B, QH, KH, QL, KL, E, causal, pad, pair)
+CASES = {
+    "plain_e64":        (0, 2, 2, 2, 128, 128, 64, False, None, False),
+    "ragged_e32":       (1, 2, 2, 2, 95, 130, 32, False, None, False),
+    "causal_e16":       (2, 2, 2, 2, 97, 97, 16, True, None, False),
+    "causal_pad_e64":   (3, 2, 2, 2, 100, 100, 64, True, "ref", False),
+    "gqa_causal_e32":   (4, 2, 6, 2, 65, 65, 32, True, None, False),
+    "pair_pad_e16":     (5, 2, 2, 2, 70, 81, 16, False, "ref", True),
+    "varlen_e128":      (6, 3, 4, 1, 80, 144, 128, False, "lens", False),
+    "deadtile_e64":     (7, 2, 2, 2, 64, 200, 64, False, "deadtile", False),
+}
+
+
+def bf16_round(x):
+    """Round fp32 to the nearest bf16-representable fp32 (round-to-nearest-even)."""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+def make_case(seed, B, QH, KH, QL, KL, E, causal, pad, pair):
+    rng = np.random.default_rng(seed)
+    g = lambda *s: bf16_round(rng.standard_normal(s).astype(np.float32))
+    d = dict(q=g(B, QH, QL, E), k=g(B, KH, KL, E), v=g(B, KH, KL, E), do=g(B, QH, QL, E))
+    d["pair"] = g(B, KL, QL, QH) if pair else np.zeros((0,), np.float32)
+    mask = np.ones((B, KL), dtype=bool)
+    if pad == "ref":            # test/attention_tests.jl:27-28
+        mask[-1, -11:] = False
+    elif pad == "lens":         # variable sequence lengths
+        lens = rng.integers(KL // 4, KL + 1, size=B)
+        mask = np.arange(KL)[None, :] < lens[:, None]
+    elif pad == "deadtile":     # a whole 64-key tile masked (the reference NaNs here; the naive formula does not)
+        mask[:, 64:128] = False
+        mask[-1, 150:] = False
+    d["mask"] = mask if pad is not None else np.zeros((0,), bool)
+    p = d["pair"].astype(np.float64) if pair else None
+    m = mask if pad is not None else None
+    o, ms, ls = naive_attention(d["q"], d["k"], d["v"], p, causal=causal, kpad_mask=m, return_stats=True)
+    dq, dk, dv, dp = naive_attention_grads(d["q"], d["k"], d["v"], d["do"], p, causal=causal, kpad_mask=m)
+    d.update(o=o.astype(np.float32), ms=ms.astype(np.float32), ls=ls.astype(np.float32),
+             dq=dq.astype(np.float32), dk=dk.astype(np.float32), dv=dv.astype(np.float32),
+             dpair=(dp.astype(np.float32) if pair else np.zeros((0,), np.float32)),
+             causal=np.array(causal))
+    return d
+
+
+def main():
+    for name, cfg in CASES.items():
+        d = make_case(*cfg)
+        np.savez_compressed(os.path.join(HERE, f"fa_{name}.npz"), **d)
+        print(name, {k: v.shape for k, v in d.items() if hasattr(v, "shape") and v.size})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""GPU tests of the operator surface: error behaviour with the reference's messages
+(src/attention.jl:141-144), residual contract, asynchronous launch on the current stream,
+nnop_shared_memory, re-entrancy from two host threads on two streams."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from util import make_inputs, oracle_fwd, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def z(dev, *s, dt=torch.bfloat16):
+    return torch.zeros(*s, dtype=dt, device=dev)
+
+
+def test_reference_error_messages(pkg, dev):
+    with pytest.raises(pkg.NNopError, match=r"Embedding dim of Q `16` must be the same as of K `32`\."):
+        pkg.flash_attention(z(dev, 1, 1, 8, 16), z(dev, 1, 1, 8, 32), z(dev, 1, 1, 8, 32), causal=False)
+    with pytest.raises(pkg.NNopError, match=r"Shapes of K `\(16, 8, 1, 1\)` and V `\(16, 9, 1, 1\)` must be the same\."):
+        pkg.flash_attention(z(dev, 1, 1, 8, 16), z(dev, 1, 1, 8, 16), z(dev, 1, 1, 9, 16), causal=False)
+    with pytest.raises(pkg.NNopError, match="Only power-of-2 embedding dims are supported."):
+        pkg.flash_attention(z(dev, 1, 1, 8, 24), z(dev, 1, 1, 8, 24), z(dev, 1, 1, 8, 24), causal=False)
+    with pytest.raises(pkg.NNopError, match="Number of query heads `3` must be divisible by number of KV heads `2`."):
+        pkg.flash_attention(z(dev, 1, 3, 8, 16), z(dev, 1, 2, 8, 16), z(dev, 1, 2, 8, 16), causal=False)
+    with pytest.raises(pkg.NNopError, match="Failed to find groupsize"):
+        pkg.flash_attention(z(dev, 1, 1, 8, 512), z(dev, 1, 1, 8, 512), z(dev, 1, 1, 8, 512), causal=False)
+    with pytest.raises(TypeError):          # mixed element types: MethodError in the reference
+        pkg.flash_attention(z(dev, 1, 1, 8, 16), z(dev, 1, 1, 8, 16, dt=torch.float16), z(dev, 1, 1, 8, 16), causal=False)
+    with pytest.raises(TypeError):
+        pkg.flash_attention(z(dev, 1, 1, 8, 16, dt=torch.float64), z(dev, 1, 1, 8, 16, dt=torch.float64),
+                            z(dev, 1, 1, 8, 16, dt=torch.float64), causal=False)
+
+
+def test_shared_memory_hook(pkg, dev):
+    """ext/NNopAMDGPUExt.jl:6-9: sharedMemPerBlock of the device."""
+    n = pkg.shared_memory(0)
+    assert n == torch.cuda.get_device_properties(0).shared_memory_per_block
+    assert n >= 64 * 1024
+
+
+def test_residuals_dtype_shape_and_meaning(pkg, dev):
+    """ms, ls are (QL,QH,B) arrays of T (src/attention.jl:167-168): ms = row max, ls = sum exp(s - ms)."""
+    for dt in ("f32", "bf16"):
+        d = make_inputs(21, 2, 2, 2, 130, 130, 32, dt, dev, need_do=False)
+        o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=True)
+        assert ms.dtype == d["q"].dtype and ls.dtype == d["q"].dtype
+        assert ms.shape == (2, 2, 130) and ls.shape == (2, 2, 130) and o.shape == d["q"].shape
+        _, ms_ref, ls_ref = oracle_fwd(d, True)
+        assert_close("ms", ms, ms_ref, dt)
+        assert_close("ls", ls, ls_ref, dt, 2.0)
+        assert (ls.float() >= 1.0 - 1e-2).all()      # the max element contributes exp(0) = 1
+
+
+def test_dead_rows_are_nan_like_the_naive_formula(pkg, dev):
+    """A row with no visible key: 0/0 = NaN in the naive formula and in the reference; a fully masked
+    K TILE alone must stay finite."""
+    d = make_inputs(22, 2, 2, 2, 64, 192, 64, "f32", dev, need_do=False)
+    m = torch.ones(2, 192, dtype=torch.bool, device=dev)
+    m[:, 64:128] = False
+    m[1, :] = False
+    d["mask"] = m
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=False, kpad_mask=m)
+    torch.cuda.synchronize()
+    o_ref, _, _ = oracle_fwd(d, False)
+    assert torch.isfinite(o[0]).all() and torch.isnan(o[1]).all()
+    assert_close("o", o, o_ref, "f32")
+    assert (ls[1] == 0).all() and torch.isneginf(ms[1]).all()
+
+
+def test_async_on_current_stream_and_thread_reentrancy(pkg, dev):
+    """The op launches on the caller's stream and never synchronises (src/attention.jl:170-176);
+    concurrent calls from two host threads on two streams give the single-threaded result."""
+    d1 = make_inputs(23, 2, 4, 4, 512, 512, 64, "bf16", dev)
+    d2 = make_inputs(24, 2, 4, 2, 384, 384, 128, "f16", dev)
+    ref1 = pkg._flash_attention(d1["q"], d1["k"], d1["v"], causal=True)[0].clone()
+    ref2 = pkg._flash_attention(d2["q"], d2["k"], d2["v"], causal=False)[0].clone()
+    torch.cuda.synchronize()
+    out, errs = {}, []
+
+    def work(name, d, causal, n):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                for _ in range(n):
+                    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=causal)
+                    g = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=causal)
+                s.synchronize()
+            out[name] = (o, g)
+        except Exception as e:                       # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=("a", d1, True, 8)), threading.Thread(target=work, args=("b", d2, False, 8))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert torch.equal(out["a"][0], ref1) and torch.equal(out["b"][0], ref2)     # deterministic, bitwise
+    g1 = pkg.grad_flash_attention(d1["do"], *pkg._flash_attention(d1["q"], d1["k"], d1["v"], causal=True),
+                                  d1["q"], d1["k"], d1["v"], causal=True)
+    for a, b in zip(out["a"][1][:3], g1[:3]):
+        assert torch.equal(a, b)                    # no atomics anywhere: gradients are bitwise reproducible
+
+
+def test_noncontiguous_inputs_are_accepted(pkg, dev):
+    d = make_inputs(25, 2, 2, 2, 100, 100, 32, "f32", dev, need_do=False)
+    qt = d["q"].transpose(1, 2).contiguous().transpose(1, 2)      # same values, permuted strides
+    assert not qt.is_contiguous()
+    a = pkg.flash_attention(qt, d["k"], d["v"], causal=False)
+    b = pkg.flash_attention(d["q"], d["k"], d["v"], causal=False)
+    assert torch.equal(a, b)

@@ -1,0 +1,89 @@
+"""GPU parity: HIP backward (through the C ABI) vs the fp64 oracle's analytic gradients, with a
+random cotangent dO (stronger than the reference's sum(o), test/attention_tests.jl:36-41).
+Grids mirror the reference's at reduced H,B plus fp16/bf16 and E=128."""
+import pytest
+import torch
+
+from util import make_inputs, oracle_bwd, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def check_bwd(pkg, d, causal, dt):
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], d["pair"], causal=causal, kpad_mask=d["mask"])
+    dq, dk, dv, dp = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], d["pair"],
+                                              causal=causal, kpad_mask=d["mask"])
+    torch.cuda.synchronize()
+    rq, rk, rv, rp = oracle_bwd(d, causal)
+    # 16-bit residuals (ms, ls in T, src/attention.jl:167-168) add a row-uniform relative error of one
+    # T-ulp to P on top of the operand rounding: allow 2x the forward tolerance for the gradients.
+    sc = 1.0 if dt == "f32" else 2.0
+    assert_close("dq", dq, rq, dt, sc)
+    assert_close("dk", dk, rk, dt, sc)
+    assert_close("dv", dv, rv, dt, sc)
+    if d["pair"] is not None:
+        assert_close("dpair", dp, rp, dt, sc)
+    else:
+        assert dp is None
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("E", [16, 32, 64, 128])
+@pytest.mark.parametrize("QL,KL", [(255, 255), (256, 512), (511, 256), (512, 1024)])
+def test_noncausal(pkg, dev, dt, E, QL, KL):
+    d = make_inputs(11, 2, 2, 2, QL, KL, E, dt, dev)
+    check_bwd(pkg, d, False, dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("E", [16, 64, 128])
+@pytest.mark.parametrize("L", [255, 256, 511, 1024])
+@pytest.mark.parametrize("pad", [None, "ref"])
+def test_causal(pkg, dev, dt, E, L, pad):
+    d = make_inputs(12, 2, 2, 2, L, L, E, dt, dev, pad=pad)
+    check_bwd(pkg, d, True, dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("QH,KH", [(4, 1), (6, 2), (8, 2)])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("L", [255, 257, 512])
+def test_gqa(pkg, dev, dt, QH, KH, causal, L):
+    d = make_inputs(13, 2, QH, KH, L, L, 32, dt, dev)
+    check_bwd(pkg, d, causal, dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("pad", ["ref", "lens", "random"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_padmask(pkg, dev, dt, pad, causal):
+    d = make_inputs(14, 3, 2, 2, 700, 700, 64, dt, dev, pad=pad)
+    check_bwd(pkg, d, causal, dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("pad", [None, "ref"])
+@pytest.mark.parametrize("E", [32, 64])
+def test_pair_and_dpair(pkg, dev, dt, causal, pad, E):
+    d = make_inputs(15, 2, 2, 2, 300, 300, E, dt, dev, pair=True, pad=pad)
+    check_bwd(pkg, d, causal, dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_rrule_through_autograd(pkg, dev, dt):
+    """src/attention_crc.jl:16-31: the pullback of flash_attention returns (dq, dk, dv, dpair)."""
+    d = make_inputs(16, 2, 4, 2, 200, 200, 64, dt, dev, pair=True, pad="ref")
+    q, k, v, pair = (d[n].clone().requires_grad_(True) for n in ("q", "k", "v", "pair"))
+    o = pkg.flash_attention(q, k, v, pair, causal=True, kpad_mask=d["mask"])
+    o.backward(d["do"])
+    torch.cuda.synchronize()
+    rq, rk, rv, rp = oracle_bwd(d, True)
+    sc = 1.0 if dt == "f32" else 2.0
+    assert_close("dq", q.grad, rq, dt, sc)
+    assert_close("dk", k.grad, rk, dt, sc)
+    assert_close("dv", v.grad, rv, dt, sc)
+    assert_close("dpair", pair.grad, rp, dt, sc)
+    with torch.no_grad():      # not under AD: plain forward, returns o only (attention_crc.jl:11-13)
+        o2 = pkg.flash_attention(d["q"], d["k"], d["v"], d["pair"], causal=True, kpad_mask=d["mask"])
+    assert torch.equal(o2, o.detach())

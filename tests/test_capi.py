@@ -1,0 +1,92 @@
+"""CPU tests of the drop-in boundary: the library loads, exports every symbol include/nnop_hip.h
+declares, and validates descriptors the way the reference's host functions do
+(src/attention.jl:141-144).  No compute call is made (no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nnop_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nnop_[a-z_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_entry_points(pkg):
+    names = declared_functions()
+    assert set(names) == set(pkg._lib.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg._lib.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in include/nnop_hip.h but not exported"
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg._lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (nnop_\w+)", out))
+    assert exported == set(declared_functions()), "exported C symbols must be exactly the header's"
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    c = tmp_path / "t.c"
+    c.write_text('#include "nnop_hip.h"\nint main(void){ nnop_fa_desc d; (void)d; return NNOP_HIP_ABI_VERSION - 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c),
+                    "-o", str(tmp_path / "t")], check=True)
+    assert subprocess.run([str(tmp_path / "t")]).returncode == 0
+
+
+def test_abi_version_and_strerror(pkg):
+    lib = pkg._lib.load()
+    assert lib.nnop_abi_version() == 1
+    assert pkg._lib.strerror(0) == "success"
+    assert "power-of-2" in pkg._lib.strerror(pkg._lib.NNOP_ERR_EMB_NOT_POW2)
+    assert "divisible" in pkg._lib.strerror(pkg._lib.NNOP_ERR_HEADS)
+    assert pkg._lib.strerror(-999) == "unknown nnop status"
+
+
+def _desc(pkg, **kw):
+    base = dict(dtype=2, emb=64, ql=128, kl=128, qh=4, kh=4, batch=1, causal=0, emb_k=0, emb_v=0, kl_v=0, kh_v=0)
+    base.update(kw)
+    return pkg._lib.FaDesc(**base)
+
+
+@pytest.mark.parametrize("kw,status", [
+    (dict(emb_k=32), "NNOP_ERR_EMB_MISMATCH"),
+    (dict(kl_v=64), "NNOP_ERR_KV_SHAPE"),
+    (dict(kh_v=2), "NNOP_ERR_KV_SHAPE"),
+    (dict(emb=48, emb_k=48), "NNOP_ERR_EMB_NOT_POW2"),
+    (dict(qh=6, kh=4), "NNOP_ERR_HEADS"),
+    (dict(dtype=7), "NNOP_ERR_DTYPE"),
+    (dict(emb=512), "NNOP_ERR_EMB_UNSUPPORTED"),
+    (dict(emb=8), "NNOP_ERR_EMB_UNSUPPORTED"),
+    (dict(ql=0), "NNOP_ERR_SHAPE"),
+    (dict(), "NNOP_ERR_NULL"),                # valid descriptor, NULL tensors
+])
+def test_descriptor_validation_order_and_codes(pkg, kw, status):
+    """Validation happens before anything touches the device, in the reference's order."""
+    lib = pkg._lib.load()
+    d = _desc(pkg, **kw)
+    null = C.c_void_p(0)
+    st = lib.nnop_fa_fwd(C.byref(d), null, null, null, null, null, null, null, null, null)
+    assert st == getattr(pkg._lib, status)
+    st = lib.nnop_fa_bwd(C.byref(d), *([null] * 13), null, 0, null)
+    assert st == getattr(pkg._lib, status)
+    if status != "NNOP_ERR_NULL":
+        assert lib.nnop_fa_bwd_workspace_bytes(C.byref(d)) == 0
+
+
+def test_workspace_bytes(pkg):
+    lib = pkg._lib.load()
+    d = _desc(pkg, ql=4096, qh=4, kh=4, batch=4)
+    assert lib.nnop_fa_bwd_workspace_bytes(C.byref(d)) == 2 * 4 * 4 * 4096 * 4
+    assert lib.nnop_fa_bwd_workspace_bytes(None) == 0
+    assert lib.nnop_fa_fwd(None, *([C.c_void_p(0)] * 9)) == pkg._lib.NNOP_ERR_NULL
+
+
+def test_shared_memory_null_pointer(pkg):
+    assert pkg._lib.load().nnop_shared_memory(0, None) == pkg._lib.NNOP_ERR_NULL
