@@ -9,9 +9,9 @@ The directory name contains a dot, so import it through ``__graft_entry__.load_p
 (registers it as module ``nnop_jl_amd``).
 """
 from .attention import (NNopError, flash_attention, _flash_attention, grad_flash_attention,
-                        shared_memory, bwd_workspace_bytes)
+                        shared_memory, bwd_workspace_bytes, fa_fwd_into, fa_bwd_into)
 from . import _lib, shard
 
 __all__ = ["NNopError", "flash_attention", "_flash_attention", "grad_flash_attention",
-           "shared_memory", "bwd_workspace_bytes", "shard", "_lib"]
+           "shared_memory", "bwd_workspace_bytes", "fa_fwd_into", "fa_bwd_into", "shard", "_lib"]
 __version__ = "0.1.0"

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnnop_hip.so")
+# NNOP_LIB_PATH: development override (timing-only ablation builds); never set in production
+LIB_PATH = os.environ.get("NNOP_LIB_PATH") or os.path.join(_HERE, "lib", "libnnop_hip.so")
 
 # nnop_dtype (include/nnop_hip.h)
 NNOP_F32, NNOP_F16, NNOP_BF16 = 0, 1, 2

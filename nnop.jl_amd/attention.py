@@ -26,7 +26,7 @@ from ._lib import FaDesc
 
 __all__ = [
     "NNopError", "flash_attention", "_flash_attention", "grad_flash_attention",
-    "shared_memory", "bwd_workspace_bytes",
+    "shared_memory", "bwd_workspace_bytes", "fa_fwd_into", "fa_bwd_into",
 ]
 
 
@@ -120,6 +120,27 @@ def shared_memory(device_id: int = 0) -> int:
 
 def bwd_workspace_bytes(q, k, v, *, causal: bool) -> int:
     return int(_lib.load().nnop_fa_bwd_workspace_bytes(C.byref(_desc(q, k, v, causal))))
+
+
+def fa_fwd_into(o, ms, ls, q, k, v, pair=None, *, causal: bool, kpad_mask=None):
+    """Raw ``nnop_fa_fwd`` into caller-owned, preallocated outputs (the C ABI's ownership model:
+    the caller allocates everything).  No checks beyond the library's own; contiguous tensors only.
+    Used by bench.py so that a timed step is exactly one library call."""
+    d = _desc(q, k, v, causal)
+    st = _lib.load().nnop_fa_fwd(C.byref(d), _ptr(o), _ptr(ms), _ptr(ls), _ptr(q), _ptr(k), _ptr(v),
+                                 _ptr(pair), _ptr(kpad_mask), _stream(q))
+    if st != _lib.NNOP_OK:
+        _raise_status(st, q, k, v)
+
+
+def fa_bwd_into(dq, dk, dv, dpair, ws, dO, o, ms, ls, q, k, v, pair=None, *, causal: bool, kpad_mask=None):
+    """Raw ``nnop_fa_bwd`` into caller-owned outputs and workspace (see fa_fwd_into)."""
+    d = _desc(q, k, v, causal)
+    st = _lib.load().nnop_fa_bwd(C.byref(d), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dpair), _ptr(dO), _ptr(o),
+                                 _ptr(ms), _ptr(ls), _ptr(q), _ptr(k), _ptr(v), _ptr(pair), _ptr(kpad_mask),
+                                 _ptr(ws), C.c_size_t(ws.numel() * ws.element_size()), _stream(q))
+    if st != _lib.NNOP_OK:
+        _raise_status(st, q, k, v)
 
 
 def _flash_attention(q, k, v, pair=None, *, causal: bool, kpad_mask=None):

@@ -229,6 +229,10 @@ __global__ __launch_bounds__(NW * 64) void fa_bwd_dkdv_kernel(const BwdParams p)
         stage_load(0);
         stage_write(bufs);
     }
+    if constexpr (kKVRegs) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { landed(kf[ks]); landed(vf[ks]); }
+    }
     __syncthreads();
 
     for (int it = 0; it < n_it; ++it) {
@@ -434,6 +438,14 @@ __global__ __launch_bounds__(NW * 64) void fa_bwd_dq_kernel(const BwdParams p) {
 
     stage_load(0);
     stage_write(bufs);
+    if constexpr (kQRegs) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { landed(qf[ks]); landed(dof[ks]); }
+    }
+    {
+        float a = nlq, b2 = ndl;
+        landed(a); landed(b2);
+    }
     __syncthreads();
 
     for (int t = 0; t < n_tiles; ++t) {

@@ -96,6 +96,12 @@ NNOP_DEV float half_swap_sum(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Force a register-resident value to have LANDED here: the compiler must insert the s_waitcnt for
+// the load that produces it at this point, not at its first use.  Used before a pipelined loop for
+// loads issued ahead of it: vmcnt retires in order, so a wait left inside the loop for an OLD load
+// would also drain the loop's own prefetch every iteration.
+template <typename V> NNOP_DEV void landed(V& v) { asm volatile("" : "+v"(v)); }
+
 template <typename T> NNOP_DEV float to_f32(T x) { return (float)x; }
 template <typename T> NNOP_DEV T from_f32(float x) { return (T)x; }
 
@@ -221,16 +227,31 @@ template <typename T, int E, int ROWS, int NT> struct Stager {
     static constexpr int kNLD = (kNCH + NT - 1) / NT;
     u32x4 reg[kNLD];
 
-    // gtile: address of row 0 of the tile; rows_valid: rows that exist (may be <= 0 or >= ROWS)
+    // gtile: address of row 0 of the tile; rows_valid: rows that exist, 1 <= rows_valid (may
+    // exceed ROWS).  Branch-free: the row index is clamped for the load and rows past the end are
+    // zeroed by a select, so no exec-masked region splits the surrounding instruction stream.
     NNOP_DEV void load(const void* gtile, int rows_valid, int tid) {
 #pragma unroll
         for (int i = 0; i < kNLD; ++i) {
-            const int c = tid + i * NT;
-            const int row = c / kN16;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            reg[i] = z;
-            if ((kNCH % NT == 0 || c < kNCH) && row < rows_valid)
-                reg[i] = *reinterpret_cast<const u32x4*>((const char*)gtile + (size_t)c * 16);
+            int c = tid + i * NT;
+            if (kNCH % NT != 0) c = c < kNCH ? c : kNCH - 1;          // surplus lanes re-read the last chunk
+            const int row = c / kN16, c16 = c % kN16;
+            const int rowc = row < rows_valid ? row : rows_valid - 1;
+            u32x4 v = *reinterpret_cast<const u32x4*>((const char*)gtile + ((size_t)rowc * kN16 + c16) * 16);
+            const bool ok = row < rows_valid;
+            reg[i][0] = ok ? v[0] : 0u;
+            reg[i][1] = ok ? v[1] : 0u;
+            reg[i][2] = ok ? v[2] : 0u;
+            reg[i][3] = ok ? v[3] : 0u;
+        }
+    }
+    // same, when the caller guarantees rows_valid >= ROWS (every row exists)
+    NNOP_DEV void load_full(const void* gtile, int tid) {
+#pragma unroll
+        for (int i = 0; i < kNLD; ++i) {
+            int c = tid + i * NT;
+            if (kNCH % NT != 0) c = c < kNCH ? c : kNCH - 1;
+            reg[i] = *reinterpret_cast<const u32x4*>((const char*)gtile + (size_t)c * 16);
         }
     }
     template <typename Img> NNOP_DEV void write(char* img, int tid) const {

@@ -14,15 +14,28 @@
 //                                                 in-register, and exp(S^T) IS the B operand of
 //                                                 O^T = V^T P^T (no LDS for S or P)
 //   O normalised after every tile (FA-1)          O un-normalised, one divide in the epilogue
-//   5 barriers / kv tile                          1 barrier / kv tile (double-buffered K,V images)
+//   5 barriers / kv tile                          1 barrier / kv tile (K ring + V ring in LDS)
 //   uncoalesced per-row loads                     16-byte coalesced tile loads, issued one tile
 //                                                 ahead, written to LDS after the compute phase
+//   QK^T, softmax, PV strictly one after the      software-pipelined across tiles INSIDE a wave:
+//   other                                         one straight-line block holds the QK^T MFMAs of
+//                                                 tile t+1, the exp/sum/convert of tile t, the PV
+//                                                 MFMAs of tile t and the row max of tile t+1, so
+//                                                 the matrix pipe and the vector pipe overlap
 //
 // Work decomposition: workgroup = NW waves = 32*NW consecutive query rows of one (batch, q-head);
 // kv tiles of BK keys; linear workgroup ids are remapped so that the workgroups sharing one
 // (batch, kv-head) -- i.e. the same K/V bytes -- run on one XCD's L2.
 #pragma once
+#include <type_traits>
 #include "fa_common.hpp"
+
+// Timing-only ablation builds (make ABL=n OUTDIR=../lib_abl): results are WRONG by construction.
+//   1 no per-interval barrier   2 no exp   3 no PV MFMAs   4 no QK^T MFMAs   5 no LDS fragment reads
+//   6 no HBM->LDS staging       7 no row-sum MFMAs          8 no row max
+#ifndef NNOP_ABL
+#define NNOP_ABL 0
+#endif
 
 namespace nnop {
 
@@ -42,23 +55,23 @@ struct FwdParams {
     float scale;             // 1/sqrt(E)
 };
 
-// kGeneral = false: KL % BK == 0, no causal, no kpad, no pair (every logit is live).
-template <typename T, int E, int NW, int BK, bool kGeneral>
-__global__ __launch_bounds__(NW * 64) void fa_fwd_kernel(const FwdParams p) {
+// MODE 0: plain   -- KL % BK == 0, no causal, no kpad, no pair: every logit is live
+// MODE 1: masked  -- causal and/or key padding and/or ragged KL
+// MODE 2: pair    -- masked + additive pair bias (logits kept pre-multiplied in log2 units)
+template <typename T, int E, int NW, int BK, int MODE>
+__global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
     using frag_t = typename Elem<T>::frag;
     using KImg   = RowImg<T, E>;
     using VImg   = ColImg<T, E>;
+    constexpr bool kGeneral = MODE != 0;
+    constexpr bool kPair = MODE == 2;
     constexpr int NT  = NW * 64;
     constexpr int KS  = E / 16;                 // contraction steps of Q K^T
     constexpr int KB  = BK / 32;                // 32-key blocks per kv tile
     constexpr int EB  = (E + 31) / 32;          // 32-column blocks of O^T
     constexpr int KBYTES = KImg::bytes(BK);
     constexpr int VBYTES = VImg::bytes(BK);
-    constexpr int TILE_BYTES = KBYTES + VBYTES;
-    constexpr int N16 = E * (int)sizeof(T) / 16;          // 16-byte chunks per row in HBM
-    constexpr int NCH = BK * N16;                          // chunks per tile per tensor
-    constexpr int NLD = (NCH + NT - 1) / NT;               // chunks per thread per tensor
-    constexpr float kThr = 0.0f;                           // defer-max threshold (log2 units)
+    constexpr uint64_t kFull = (BK < 64) ? ((1ull << BK) - 1ull) : ~0ull;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -80,204 +93,416 @@ __global__ __launch_bounds__(NW * 64) void fa_fwd_kernel(const FwdParams p) {
     const int qi_c = qi < p.QL ? qi : p.QL - 1;            // clamped for loads
 
     const T* __restrict__ qp = (const T*)p.q + ((size_t)bh * p.QL) * E;
-    const T* __restrict__ kp = (const T*)p.k + ((size_t)(b * p.KH + kvh) * p.KL) * E;
-    const T* __restrict__ vp = (const T*)p.v + ((size_t)(b * p.KH + kvh) * p.KL) * E;
+    const char* __restrict__ kp = (const char*)((const T*)p.k + ((size_t)(b * p.KH + kvh) * p.KL) * E);
+    const char* __restrict__ vp = (const char*)((const T*)p.v + ((size_t)(b * p.KH + kvh) * p.KL) * E);
     const uint8_t* __restrict__ mp = kGeneral && p.kpad ? p.kpad + (size_t)b * p.KL : nullptr;
+
+    char* const kring = smem;
+    char* const vring = smem + 2 * KBYTES;
 
     // ---- number of kv tiles this workgroup walks ---------------------------------------
     int n_tiles = (p.KL + BK - 1) / BK;
+    if constexpr (kGeneral) {
+        if (p.causal) {
+            int q_last = qblk * (32 * NW) + 32 * NW - 1;
+            if (q_last > p.QL - 1) q_last = p.QL - 1;
+            const int t_c = q_last / BK + 1;                   // keys <= q_last
+            if (t_c < n_tiles) n_tiles = t_c;
+        }
+        if (mp) {
+            // variable sequence length: stop after the tile holding the last valid key
+            int* slot = reinterpret_cast<int*>(smem + 2 * KBYTES + 2 * VBYTES);
+            if (tid == 0) *slot = -1;
+            __syncthreads();
+            int last = -1;
+            for (int i = tid; i < n_tiles * BK && i < p.KL; i += NT)
+                if (mp[i]) last = i;
+            if (last >= 0) atomicMax(slot, last);
+            __syncthreads();
+            const int t_m = *slot / BK + 1;                    // *slot == -1 -> 0 tiles -> NaN rows
+            if (t_m < n_tiles) n_tiles = t_m;
+        }
+    }
+    // tiles that are live for THIS wave (causal: up to its own diagonal)
+    int n_live = n_tiles;
     if (kGeneral && p.causal) {
-        int q_last = qblk * (32 * NW) + 32 * NW - 1;
-        if (q_last > p.QL - 1) q_last = p.QL - 1;
-        const int t_c = q_last / BK + 1;                   // keys <= q_last
-        if (t_c < n_tiles) n_tiles = t_c;
+        const int t_w = (q0w + 31) / BK + 1;
+        if (t_w < n_live) n_live = t_w;
     }
 
-    // ---- Q fragments: B operand of S^T = K Q^T, straight from HBM into registers --------
+    // ---- Q fragments: B operand of S^T = K Q^T, straight from HBM into registers, PRE-SCALED by
+    // c2 = scale * log2(e) (one rounding to T per element, once per kernel): the MFMA then produces
+    // logits in log2 units and P = exp2(S') needs no per-element multiply.
+    const float c2 = p.scale * kLog2e;
     frag_t qf[KS];
     {
         const T* qrow = qp + (size_t)qi_c * E;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const frag_t*>(qrow + 16 * ks + 8 * h);
+        for (int ks = 0; ks < KS; ++ks) {
+            const frag_t raw = *reinterpret_cast<const frag_t*>(qrow + 16 * ks + 8 * h);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[ks][j] = from_f32<T>(to_f32(raw[j]) * c2);
+        }
     }
 
-    // ---- staging: thread -> 16-byte chunks of the [BK][E] K and V tiles -----------------
-    u32x4 kreg[NLD], vreg[NLD];
-    auto stage_load = [&](int t) {
-        const int k0 = t * BK;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int c = tid + i * NT;
-            const int row = c / N16;
-            const bool ok = (NCH % NT == 0 || c < NCH) && (!kGeneral || k0 + row < p.KL);
-            u32x4 z = {0u, 0u, 0u, 0u};
-            kreg[i] = z;
-            vreg[i] = z;
-            if (ok) {
-                const size_t off = ((size_t)k0 * N16 + c) * 16;
-                kreg[i] = *reinterpret_cast<const u32x4*>((const char*)kp + off);
-                vreg[i] = *reinterpret_cast<const u32x4*>((const char*)vp + off);
-            }
-        }
-    };
-    auto stage_write = [&](char* buf) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int c = tid + i * NT;
-            if (NCH % NT == 0 || c < NCH) {
-                const int row = c / N16, c16 = c % N16;
-                KImg::write16(buf, row, c16, kreg[i]);
-                VImg::write16(buf + KBYTES, row, c16, vreg[i]);
-            }
-        }
+    // ---- staging (K runs ONE TILE AHEAD of V) ---------------------------------------------
+    //   interval t (between two barriers) reads K(t+1) and V(t); at its end K(t+2) replaces K(t)
+    //   and V(t+1) replaces V(t-1): a K ring of 2 and a V ring of 2.  The HBM/L2 loads run one
+    //   interval further ahead than the LDS writes (two register sets): K(t+3), V(t+2) are requested
+    //   at the top of interval t and written at the end of interval t+1, so a load has two intervals
+    //   to land (one interval alone does not cover the L2 latency under load).
+    // kPipe: software-pipelined body (two score tiles live).  Needs the registers: 16-bit types,
+    // E <= 64 in every mode, E = 128 in plain mode only.  Everything else (fp32, whose MFMAs are 16x
+    // longer and already dominate; E = 128 masked) runs one tile per interval: X(t) then Y(t).
+    constexpr bool kPipe = sizeof(T) == 2 && (E <= 64 || MODE == 0);
+    constexpr bool kDeep = kPipe && MODE == 0 && E <= 64 && NW == 8;
+    Stager<T, E, BK, NT> sk0, sv0, sk1, sv1;
+    auto stage = [&](Stager<T, E, BK, NT>& st, const char* base, int t) {
+        if constexpr (kGeneral) st.load(base + (size_t)t * ((size_t)BK * E * sizeof(T)), p.KL - t * BK, tid);
+        else st.load_full(base + (size_t)t * ((size_t)BK * E * sizeof(T)), tid);
     };
 
-    // ---- per-lane LDS read addresses -----------------------------------------------------
     const int vbase = VImg::lane_base(lane);
 
-    // ---- accumulators ---------------------------------------------------------------------
     f32x16 oacc[EB];
 #pragma unroll
     for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[eb][i] = 0.f;
-    float m2 = -INFINITY;      // running max, log2 units, shared by lanes r and r+32
-    float lsum = 0.f;          // running sum over THIS lane's keys only (halves added at the end)
-    const float c2 = p.scale * kLog2e;
+    // Deferred-max online softmax.  m2 is the exponent REFERENCE (log2 units, per query row, shared
+    // by lanes r and r+32); -m2 is the INITIAL ACCUMULATOR of the QK^T MFMA chain (`cinit`, 16 equal
+    // registers), so the accumulators hold S' = S - m2 and P = exp2(S') costs one v_exp and nothing
+    // else.  The reference is raised only when a row's max outgrows it by more than kThr (then
+    // P <= 2^kThr: exact for the fp32 accumulation, inside fp16/bf16 range), or adopted exactly at
+    // the row's first visible key.  mt is the TRUE running row max, kept because the residual
+    // contract wants it (ms = row max, src/attention.jl:128).
+    constexpr float kThr = 8.0f;
+    constexpr bool kMfmaSum = sizeof(T) == 2 && MODE == 0 && E <= 64;   // row sums on the matrix pipe (all-ones A operand)
+    float m2 = 0.f;
+    float mt = -INFINITY;
+    float lsum = 0.f;          // VALU row sum over THIS lane's keys (fp32 path; halves added at the end)
+    f32x16 cinit, lacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { cinit[i] = 0.f; lacc[i] = 0.f; }
+    frag_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = from_f32<T>(1.0f);
 
-    stage_load(0);
-    stage_write(smem);
-    __syncthreads();
-
-    for (int t = 0; t < n_tiles; ++t) {
-        char* cur = smem + (t & 1) * TILE_BYTES;
-        char* nxt = smem + ((t + 1) & 1) * TILE_BYTES;
-        const bool more = t + 1 < n_tiles;
-        if (more) stage_load(t + 1);
-
-        const int k0 = t * BK;
-        // wave-uniform tile classification (general mode only)
-        bool skip = false, need_mask = false;
-        uint64_t valid = ~0ull;
+    // ---- X(t): S^T = K Q^T for kv tile t (MFMA) ---------------------------------------------
+    // LDS fragment reads are issued EARLY (kf_load / vf_load at the top of an interval, pinned by a
+    // sched_barrier) and consumed late: one LDS round trip (~100+ cycles under load) in front of
+    // every MFMA was the dominant stall of the un-prefetched loop.  fp32 keeps fragments in flight
+    // only one MFMA group ahead (its MFMAs are 16x longer, and its fragments 2x the registers).
+    constexpr int NKF = KB * KS;                       // K fragments per tile
+    constexpr int NVF = EB * 2 * KB;                   // V fragments per tile
+    // (register budget: only the plain variants have room; E=128 prefetches half as many)
+    constexpr bool kPrefetch = sizeof(T) == 2 && MODE == 0 && E <= 64;
+    constexpr int kPfMax = 8;
+    constexpr int PFK = kPrefetch ? (NKF <= kPfMax ? NKF : kPfMax) : 0;   // fragments prefetched to registers
+    constexpr int PFV = kPrefetch ? (NVF <= kPfMax ? NVF : kPfMax) : 0;
+    auto kf_load = [&](const char* kimg, frag_t (&kf)[PFK > 0 ? PFK : 1]) {
+#pragma unroll
+#if NNOP_ABL != 5
+        for (int f = 0; f < PFK; ++f) kf[f] = KImg::read_row_frag(kimg, 32 * (f / KS) + r, h, f % KS);
+#else
+        for (int f = 0; f < PFK; ++f) kf[f] = qf[f % KS];
+#endif
+    };
+    auto vf_load = [&](const char* vimg, frag_t (&vf)[PFV > 0 ? PFV : 1]) {
+#pragma unroll
+#if NNOP_ABL != 5
+        for (int f = 0; f < PFV; ++f) vf[f] = VImg::read_col_frag(vimg + vbase, f % (2 * KB), f / (2 * KB));
+#else
+        for (int f = 0; f < PFV; ++f) vf[f] = qf[f % KS];
+#endif
+    };
+    auto qk_tile = [&](const char* kimg, const frag_t (&kf)[PFK > 0 ? PFK : 1], f32x16 (&s)[KB]) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int f = kb * KS + ks;
+                frag_t a;
+                if (f < PFK) a = kf[f < PFK ? f : 0];
+                else a = KImg::read_row_frag(kimg, 32 * kb + r, h, ks);
+#if NNOP_ABL != 4
+                s[kb] = mma16<T>(a, qf[ks], ks == 0 ? cinit : s[kb]);     // S' = K Q^T - m2
+#else
+                if (ks == 0) s[kb] = cinit;
+                s[kb][ks] += (float)a[0];
+#endif
+            }
+        }
+    };
+    // wave-uniform: which keys of tile t are valid (bounds + key padding); does it need masking
+    auto tile_valid = [&](int t) -> uint64_t {
+        uint64_t valid = kFull;
         if constexpr (kGeneral) {
-            if (p.causal && k0 > q0w + 31) skip = true;                 // tile entirely above diagonal
-            if (BK < 64) valid = (1ull << BK) - 1ull;
+            const int k0 = t * BK;
             if (k0 + BK > p.KL) valid &= (p.KL - k0 >= 64) ? ~0ull : ((1ull << (p.KL - k0)) - 1ull);
             if (mp) {
                 const int kk = k0 + lane;
                 const bool lv = (lane < BK && kk < p.KL) ? (mp[kk] != 0) : false;
                 valid &= __ballot(lv);
             }
-            if (valid == 0ull) skip = true;
-            need_mask = (valid != ((BK < 64) ? ((1ull << BK) - 1ull) : ~0ull)) ||
-                        (p.causal && k0 + BK - 1 > q0w) || (p.pair != nullptr);
         }
-
-        if (!skip) {
-            // ---- S^T = K Q^T : keys in registers, query on the lane -----------------------
-            f32x16 s[KB];
+        return valid;
+    };
+    auto tile_needs_mask = [&](int t, uint64_t valid) {
+        return kGeneral && (valid != kFull || (p.causal && t * BK + BK - 1 > q0w));
+    };
+    // mask (-> -inf) / bias tile t in place and return max(S') over the row (both halves): the
+    // row max relative to the reference the tile was computed against.
+    auto finish_x = [&](auto masked, f32x16 (&s)[KB], int t, uint64_t valid) -> float {
+        constexpr bool MASKED = decltype(masked)::value;
+        const int k0 = t * BK;
+        float mxp[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // 4 independent chains
+        if constexpr (MASKED || kPair) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
+                const uint32_t w = (uint32_t)(valid >> (32 * kb + 4 * h));
+                const int lim = qi - k0 - 32 * kb - 4 * h;                  // causal: local row <= lim
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    frag_t kf = KImg::read_row_frag(cur, 32 * kb + r, h, ks);
-                    s[kb] = mma16<T>(kf, qf[ks], s[kb]);
-                }
-            }
-
-            // ---- logits in log2 units, masks ----------------------------------------------
-            float mx = -INFINITY;
-            if constexpr (kGeneral) {
-                if (need_mask) {
-#pragma unroll
-                    for (int kb = 0; kb < KB; ++kb) {
-                        const uint32_t w = (uint32_t)(valid >> (32 * kb + 4 * h));
-                        const int lim = qi - k0 - 32 * kb - 4 * h;   // causal: local row <= lim
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            constexpr int dummy = 0; (void)dummy;
-                            const int lr = (i & 3) + 8 * (i >> 2);
-                            bool ok = (w >> lr) & 1u;
-                            if (p.causal) ok = ok && (lr <= lim);
-                            float x = s[kb][i] * c2;
-                            if (p.pair) {
-                                const int key = k0 + 32 * kb + lr + 4 * h;
-                                if (ok && qi < p.QL) {
-                                    const size_t po = (((size_t)b * p.KL + key) * p.QL + qi) * p.QH + qh;
-                                    x += to_f32(((const T*)p.pair)[po]) * kLog2e;
-                                }
-                            }
-                            s[kb][i] = ok ? x : -INFINITY;
-                            mx = fmaxf(mx, s[kb][i]);
+                for (int i = 0; i < 16; ++i) {
+                    const int lr = (i & 3) + 8 * (i >> 2);
+                    bool ok = true;
+                    if constexpr (MASKED) {
+                        ok = (w >> lr) & 1u;
+                        if (p.causal) ok = ok && (lr <= lim);
+                    }
+                    float x = s[kb][i];
+                    if constexpr (kPair) {
+                        const int key = k0 + 32 * kb + lr + 4 * h;
+                        if (ok && qi < p.QL && key < p.KL) {
+                            const size_t po = (((size_t)b * p.KL + key) * p.QL + qi) * p.QH + qh;
+                            x += to_f32(((const T*)p.pair)[po]) * kLog2e;
                         }
                     }
+                    s[kb][i] = ok ? x : -INFINITY;
+                    mxp[i & 3] = fmaxf(mxp[i & 3], s[kb][i]);
                 }
             }
-            const bool premul = kGeneral && need_mask;     // s already in log2 units
-            if (!premul) {
+        } else {
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
-                mx *= c2;
+                for (int i = 0; i < 16; i += 2)
+                    mxp[(i >> 1) & 3] = fmaxf(fmaxf(mxp[(i >> 1) & 3], s[kb][i]), s[kb][i + 1]);
+        }
+        return half_swap_max(fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3])));
+    };
+    // Y(t): exp / convert / O^T += V^T P^T (+ row sums) for tile t, one 16-key step at a time so
+    // that the exps of step kk+1 sit beside the MFMAs of step kk.
+    auto softmax_pv = [&](f32x16 (&s)[KB], const char* vimg, const frag_t (&vfp)[PFV > 0 ? PFV : 1]) {
+        float lp[4] = {0.f, 0.f, 0.f, 0.f};                                  // 4 independent chains
+        const char* vb = vimg + vbase;
+#pragma unroll
+        for (int kk = 0; kk < 2 * KB; ++kk) {
+            const int kb = kk >> 1, i0 = 8 * (kk & 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#if NNOP_ABL != 2
+                s[kb][i0 + j] = fast_exp2(s[kb][i0 + j]);
+#endif
+                if constexpr (!kMfmaSum) lp[j & 3] += s[kb][i0 + j];
             }
-            mx = half_swap_max(mx);
-
-            // ---- online softmax: rescale only when some row's max grew ---------------------
-            if (__any(mx > m2 + kThr)) {
-                const float mn = fmaxf(m2, mx);
-                const float alpha = (mn == -INFINITY) ? 1.f : fast_exp2(m2 - mn);
+            // P^T comes straight from the S^T accumulators (acc_frag): no LDS, no lane movement
+            const frag_t pf = (kk & 1) ? acc_frag<T, 1>(s[kb]) : acc_frag<T, 0>(s[kb]);
+            // row sums: ones[32 x 16] * P^T -> every accumulator row holds sum_k P^T[k][query]
+#if NNOP_ABL != 7
+            if constexpr (kMfmaSum) lacc = mma16<T>(ones, pf, lacc);
+#else
+            lacc[0] += (float)pf[0];
+#endif
 #pragma unroll
-                for (int eb = 0; eb < EB; ++eb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) oacc[eb][i] *= alpha;
-                lsum *= alpha;
-                m2 = mn;
+            for (int eb = 0; eb < EB; ++eb) {
+                const int f = eb * 2 * KB + kk;
+                frag_t vf;
+                if (f < PFV) vf = vfp[f < PFV ? f : 0];
+                else vf = VImg::read_col_frag(vb, kk, eb);
+#if NNOP_ABL != 3
+                oacc[eb] = mma16<T>(vf, pf, oacc[eb]);
+#else
+                oacc[eb][kk] += (float)vf[0] * (float)pf[0];
+#endif
             }
-            const float msub = (kGeneral && m2 == -INFINITY) ? 0.f : m2;
-            if (premul) {
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        s[kb][i] = fast_exp2(s[kb][i] - msub);
-                        lsum += s[kb][i];
-                    }
-            } else {
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        s[kb][i] = fast_exp2(__builtin_fmaf(s[kb][i], c2, -msub));
-                        lsum += s[kb][i];
-                    }
-            }
-
-            // ---- O^T += V^T P^T : P^T comes straight from the S^T accumulators -------------
-            frag_t pf[2 * KB];
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                pf[2 * kb]     = acc_frag<T, 0>(s[kb]);
-                pf[2 * kb + 1] = acc_frag<T, 1>(s[kb]);
-            }
-            const char* vb = cur + KBYTES + vbase;
+        }
+        if constexpr (!kMfmaSum) lsum += (lp[0] + lp[1]) + (lp[2] + lp[3]);
+    };
+    // Top of interval t: `sc` holds S'(t) relative to the current reference m2 and `mxr` its row
+    // max.  Rare path: some row's max outgrew the reference by > kThr, or a row meets its first
+    // visible key -> move the reference.  Everything at the old reference is shifted exactly once:
+    // O, l (accumulated so far), the not-yet-exponentiated S'(t), and the MFMA initial accumulator.
+    auto rescale = [&](f32x16 (&sc)[KB], float mxr) {
+        const bool first = (mt == -INFINITY) && (mxr != -INFINITY);
+        mt = fmaxf(mt, m2 + mxr);
+        if (__any(mxr > kThr || first)) {
+            const float d = first ? mxr : fmaxf(mxr, 0.f);       // reference moves by d (log2 units)
+            const float dd = (d == -INFINITY) ? 0.f : d;
+            const float alpha = first ? 1.f : fast_exp2(-dd);     // nothing accumulated before `first`
 #pragma unroll
             for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
-                for (int kk = 0; kk < 2 * KB; ++kk) {
-                    frag_t vf = VImg::read_col_frag(vb, kk, eb);
-                    oacc[eb] = mma16<T>(vf, pf[kk], oacc[eb]);
-                }
+                for (int i = 0; i < 16; ++i) oacc[eb][i] *= alpha;
+            if constexpr (kMfmaSum) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
+            } else {
+                lsum *= alpha;
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sc[kb][i] -= dd;
+            m2 += dd;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cinit[i] = -m2;
         }
+    };
 
-        if (more) stage_write(nxt);
+    if constexpr (!kPipe) {
+        // ---- one tile per interval: K(t), V(t) in ring slot t&1; K(t+1), V(t+1) requested at the top
+        // of interval t and written to the other slot at its end (one barrier per tile).
+        if (n_tiles > 0) {
+            stage(sk0, kp, 0);
+            stage(sv0, vp, 0);
+            sk0.template write<KImg>(kring, tid);
+            sv0.template write<VImg>(vring, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) landed(qf[ks]);
         __syncthreads();
+        for (int t = 0; t < n_tiles; ++t) {
+            const bool more1 = t + 1 < n_tiles;
+            if (more1) { stage(sk0, kp, t + 1); stage(sv0, vp, t + 1); }
+            if (t < n_live) {
+                f32x16 sc[KB];
+                frag_t nokf[1], novf[1];
+                qk_tile(kring + (t & 1) * KBYTES, nokf, sc);
+                const uint64_t vt = tile_valid(t);
+                float mxr;
+                if (tile_needs_mask(t, vt)) mxr = finish_x(std::true_type{}, sc, t, vt);
+                else mxr = finish_x(std::false_type{}, sc, t, vt);
+                rescale(sc, mxr);
+                softmax_pv(sc, vring + (t & 1) * VBYTES, novf);
+            }
+            if (more1) {
+                sk0.template write<KImg>(kring + ((t + 1) & 1) * KBYTES, tid);
+                sv0.template write<VImg>(vring + ((t + 1) & 1) * VBYTES, tid);
+            }
+            __syncthreads();
+        }
+    } else {
+    // ---- prologue: K(0), V(0), K(1) -> LDS; K(2), V(1) -> register set 1; X(0) ------------------
+    f32x16 sa[KB], sb[KB];
+    float mxa = -INFINITY, mxb = -INFINITY;
+    if (n_tiles > 0) {
+        stage(sk0, kp, 0);
+        stage(sv0, vp, 0);
+        if (n_tiles > 1) stage(sk1, kp, 1);
+        sk0.template write<KImg>(kring, tid);
+        sv0.template write<VImg>(vring, tid);
+        if (n_tiles > 1) {
+            sk1.template write<KImg>(kring + KBYTES, tid);
+            if constexpr (kDeep) stage(sv1, vp, 1);
+        }
+        if constexpr (kDeep) {
+            if (n_tiles > 2) stage(sk1, kp, 2);
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) landed(qf[ks]);
+    __syncthreads();
+    if (n_live > 0) {
+        frag_t kf0[PFK > 0 ? PFK : 1];
+        kf_load(kring, kf0);
+        qk_tile(kring, kf0, sa);
+        const uint64_t v0 = tile_valid(0);
+        if (tile_needs_mask(0, v0)) mxa = finish_x(std::true_type{}, sa, 0, v0);
+        else mxa = finish_x(std::false_type{}, sa, 0, v0);
+    }
+    __syncthreads();      // every wave has read K(0) before interval 0 ends by overwriting it
+
+    // one interval: Y(t) on `sc` (row max `mxc` known) together with X(t+1) into `sn` / `mxn`.
+    // (skl, svl): register set loaded this interval; (skw, svw): set written at its end.
+    auto interval = [&](int t, f32x16 (&sc)[KB], float mxc, f32x16 (&sn)[KB], float& mxn,
+                        Stager<T, E, BK, NT>& skl, Stager<T, E, BK, NT>& svl,
+                        Stager<T, E, BK, NT>& skw, Stager<T, E, BK, NT>& svw) {
+        const bool more1 = t + 1 < n_tiles, more2 = t + 2 < n_tiles, more3 = t + 3 < n_tiles;
+#if NNOP_ABL != 6
+        if constexpr (kDeep) {
+            if (more3) stage(skl, kp, t + 3);
+            if (more2) stage(svl, vp, t + 2);
+        } else {
+            if (more2) stage(skw, kp, t + 2);
+            if (more1) stage(svw, vp, t + 1);
+        }
+#endif
+        const char* knext = kring + ((t + 1) & 1) * KBYTES;
+        const char* vcur = vring + (t & 1) * VBYTES;
+        frag_t kfr[PFK > 0 ? PFK : 1], vfr[PFV > 0 ? PFV : 1];
+        if constexpr (!kGeneral) {
+            rescale(sc, mxc);
+            // ONE basic block: LDS fragment reads first, then QK^T(t+1) MFMAs | exp, convert (t)
+            // | PV(t) MFMAs | row max (t+1).  Past the last tile the K ring holds a stale tile: the
+            // result is never used.
+            kf_load(knext, kfr);
+            vf_load(vcur, vfr);
+            __builtin_amdgcn_sched_barrier(0);
+            qk_tile(knext, kfr, sn);
+            softmax_pv(sc, vcur, vfr);
+#if NNOP_ABL != 8
+            mxn = finish_x(std::false_type{}, sn, t + 1, kFull);
+#else
+            mxn = sn[0][0];
+#endif
+        } else {
+            if (t < n_live) {
+                rescale(sc, mxc);
+                if (t + 1 < n_live) {
+                    const uint64_t vn = tile_valid(t + 1);
+                    const bool nm = tile_needs_mask(t + 1, vn);
+                    kf_load(knext, kfr);
+                    vf_load(vcur, vfr);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nm) {
+                        qk_tile(knext, kfr, sn);
+                        softmax_pv(sc, vcur, vfr);
+                        mxn = finish_x(std::true_type{}, sn, t + 1, vn);
+                    } else {
+                        qk_tile(knext, kfr, sn);
+                        softmax_pv(sc, vcur, vfr);
+                        mxn = finish_x(std::false_type{}, sn, t + 1, vn);
+                    }
+                } else {
+                    vf_load(vcur, vfr);
+                    softmax_pv(sc, vcur, vfr);
+                }
+            }
+        }
+#if NNOP_ABL != 6
+        if (more2) skw.template write<KImg>(kring + (t & 1) * KBYTES, tid);
+        if (more1) svw.template write<VImg>(vring + ((t + 1) & 1) * VBYTES, tid);
+#endif
+#if NNOP_ABL != 1
+        __syncthreads();
+#endif
+    };
+
+    for (int t = 0; t < n_tiles; t += 2) {
+        if constexpr (kDeep) {
+            interval(t, sa, mxa, sb, mxb, sk0, sv0, sk1, sv1);
+            if (t + 1 < n_tiles) interval(t + 1, sb, mxb, sa, mxa, sk1, sv1, sk0, sv0);
+        } else {        // one register set: loaded at the top of an interval, written at its end
+            interval(t, sa, mxa, sb, mxb, sk0, sv0, sk0, sv0);
+            if (t + 1 < n_tiles) interval(t + 1, sb, mxb, sa, mxa, sk0, sv0, sk0, sv0);
+        }
     }
 
+    }   // kPipe
+
     // ---- epilogue: normalise, store o, ms, ls -----------------------------------------------
-    const float ltot = half_swap_sum(lsum);
+    const float ltot = kMfmaSum ? lacc[0] : half_swap_sum(lsum);
     const float inv = 1.0f / ltot;                         // ltot == 0 (no visible key) -> NaN rows,
                                                            // as the naive formula gives
     if (qi < p.QL) {
@@ -288,14 +513,12 @@ __global__ __launch_bounds__(NW * 64) void fa_fwd_kernel(const FwdParams p) {
             for (int g = 0; g < 4; ++g) {
                 const int e = 32 * eb + 8 * g + 4 * h;
                 if (e < E) {
+                    f32x4 w = {oacc[eb][4 * g] * inv, oacc[eb][4 * g + 1] * inv,
+                               oacc[eb][4 * g + 2] * inv, oacc[eb][4 * g + 3] * inv};
                     if constexpr (sizeof(T) == 4) {
-                        f32x4 w = {oacc[eb][4 * g] * inv, oacc[eb][4 * g + 1] * inv,
-                                   oacc[eb][4 * g + 2] * inv, oacc[eb][4 * g + 3] * inv};
                         *reinterpret_cast<f32x4*>(orow + e) = w;
                     } else {
                         typedef T t4 __attribute__((ext_vector_type(4)));
-                        f32x4 w = {oacc[eb][4 * g] * inv, oacc[eb][4 * g + 1] * inv,
-                                   oacc[eb][4 * g + 2] * inv, oacc[eb][4 * g + 3] * inv};
                         *reinterpret_cast<t4*>(orow + e) = __builtin_convertvector(w, t4);
                     }
                 }
@@ -305,20 +528,20 @@ __global__ __launch_bounds__(NW * 64) void fa_fwd_kernel(const FwdParams p) {
             // ls = sum exp(s - ms), both in T.  ms is rounded to T first and ls is expressed
             // relative to the ROUNDED ms, so the pair stays self-consistent in 16-bit types.
             const size_t so = (size_t)bh * p.QL + qi;
-            const float m_nat = m2 * kLn2;
+            const float m_nat = mt * kLn2;
             const T m_t = from_f32<T>(m_nat);
             const float m_back = to_f32(m_t);
-            float l_out = ltot;
-            if (m2 != -INFINITY) l_out = ltot * fast_exp2((m_nat - m_back) * kLog2e);
+            float l_out = ltot;                            // sum exp2(x - m2) -> sum exp(s - ms)
+            if (mt != -INFINITY) l_out = ltot * fast_exp2(m2 - m_back * kLog2e);
             ((T*)p.ms)[so] = m_t;
             ((T*)p.ls)[so] = from_f32<T>(l_out);
         }
     }
 }
 
-// LDS bytes the kernel needs (two buffers of a K image + a V image).
+// LDS bytes the kernel needs (K ring of 2 + V ring of 2 + one scratch slot).
 template <typename T, int E, int BK> constexpr int fa_fwd_lds_bytes() {
-    return 2 * (RowImg<T, E>::bytes(BK) + ColImg<T, E>::bytes(BK));
+    return 2 * (RowImg<T, E>::bytes(BK) + ColImg<T, E>::bytes(BK)) + 16;
 }
 
 }  // namespace nnop

@@ -12,12 +12,14 @@
 
 namespace nnop {
 
-template <typename T, int E, int NW, bool kGeneral>
+template <typename T, int E, int NW, int MODE>
 static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
-    constexpr int BK = 64;
+    // 64-key tiles, except where the masked body would not fit 256 VGPRs (E = 128) and fp32 E = 128
+    // (LDS: 2 x (K + V) x 64 keys x 512 B = 128 KiB would leave one workgroup per CU)
+    constexpr int BK = (E >= 128 && (MODE != 0 || sizeof(T) == 4)) ? 32 : 64;
     constexpr int lds = fa_fwd_lds_bytes<T, E, BK>();
     static_assert(lds <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
-    auto kern = fa_fwd_kernel<T, E, NW, BK, kGeneral>;
+    auto kern = fa_fwd_kernel<T, E, NW, BK, MODE>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             (void)hipGetLastError();
@@ -34,23 +36,30 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.n_wg = (int)n_wg;
     p.scale = (float)(1.0 / sqrt((double)E));        // T(inv(sqrt(QE))), src/attention.jl:154
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, s, p);
+    const int lds_pad = env_int("NNOP_FWD_LDS_PAD", 0);   // debugging aid: limits workgroups per CU
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds + lds_pad, s, p);
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
 template <typename T, int E>
 static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
-    const bool general = d.causal || a.kpad || a.pair || (d.kl % 64) != 0;
+    // 0 = plain (every logit live), 1 = masked (causal / key padding / ragged KL), 2 = + pair bias
+    const int mode = a.pair ? 2 : ((d.causal || a.kpad || (d.kl % 64) != 0) ? 1 : 0);
     // waves per workgroup: 8 (256 query rows) when that still yields >= one workgroup per CU,
     // else 4 (128 rows) so that small problems spread over more CUs.
     int nw = 8;
     const long long wg8 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
     if (wg8 < 256 || d.ql <= 128) nw = 4;
+    if (E >= 128 && mode != 0) nw = 4;      // the masked E=128 body needs > 256 VGPRs at 2 waves per SIMD
     nw = env_int("NNOP_FWD_NW", nw);
     if (nw == 8) {
-        return general ? launch_fwd_cfg<T, E, 8, true>(d, a, s) : launch_fwd_cfg<T, E, 8, false>(d, a, s);
+        if (mode == 0) return launch_fwd_cfg<T, E, 8, 0>(d, a, s);
+        if (mode == 1) return launch_fwd_cfg<T, E, 8, 1>(d, a, s);
+        return launch_fwd_cfg<T, E, 8, 2>(d, a, s);
     }
-    return general ? launch_fwd_cfg<T, E, 4, true>(d, a, s) : launch_fwd_cfg<T, E, 4, false>(d, a, s);
+    if (mode == 0) return launch_fwd_cfg<T, E, 4, 0>(d, a, s);
+    if (mode == 1) return launch_fwd_cfg<T, E, 4, 1>(d, a, s);
+    return launch_fwd_cfg<T, E, 4, 2>(d, a, s);
 }
 
 template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {

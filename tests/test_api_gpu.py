@@ -110,3 +110,26 @@ def test_noncontiguous_inputs_are_accepted(pkg, dev):
     a = pkg.flash_attention(qt, d["k"], d["v"], causal=False)
     b = pkg.flash_attention(d["q"], d["k"], d["v"], causal=False)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("E,causal,pad", [(64, False, None), (64, True, None), (64, False, "ref"), (128, True, None),
+                                          (32, True, "lens"), (16, False, None)])
+def test_bitwise_reproducible_across_launches_and_workgroup_shapes(pkg, dev, dt, E, causal, pad, monkeypatch):
+    """No atomics and no cross-workgroup reduction anywhere: repeated launches are bitwise identical,
+    also right after the caches were flushed, and the 4-wave and 8-wave forward variants (same per-row
+    arithmetic, different workgroup shape) agree bitwise.  Guards against races / hazards that a
+    tolerance check can miss."""
+    d = make_inputs(31, 2, 4, 2, 517, 517, E, dt, dev, pad=pad)
+    flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
+    outs = []
+    for nw in ("8", "4", "4", "8"):
+        monkeypatch.setenv("NNOP_FWD_NW", nw)
+        flush.fill_(1)
+        o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=causal, kpad_mask=d["mask"])
+        g = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=causal, kpad_mask=d["mask"])
+        torch.cuda.synchronize()
+        outs.append((o, ms, ls) + tuple(g[:3]))
+    for other in outs[1:]:
+        for a, b, name in zip(outs[0], other, ("o", "ms", "ls", "dq", "dk", "dv")):
+            assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), name
