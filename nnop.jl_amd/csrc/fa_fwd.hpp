@@ -7,30 +7,37 @@
 //
 //   reference (attention.jl)                      this kernel
 //   -----------------------------------------    ---------------------------------------------
-//   1 thread = 1 query row, scalar FMAs out of    1 wave = 32 query rows, both contractions on
-//   LDS (mma!, mma.jl:6-48), T accumulation       MFMA 32x32x16 (bf16/f16) / 32x32x2 (f32), fp32 acc
+//   1 thread = 1 query row, scalar FMAs out of    1 wave = QB blocks of 32 query rows, both
+//   LDS (mma!, mma.jl:6-48), T accumulation       contractions on MFMA 32x32x16 (bf16/f16) /
+//                                                 32x32x2 (f32), fp32 accumulation
 //   S, P round-trip through s_shm                 S^T = K Q^T ("swapped"): the query sits on the
 //                                                 lane, its 32 keys in registers -> softmax is
 //                                                 in-register, and exp(S^T) IS the B operand of
 //                                                 O^T = V^T P^T (no LDS for S or P)
 //   O normalised after every tile (FA-1)          O un-normalised, one divide in the epilogue
 //   5 barriers / kv tile                          1 barrier / kv tile (K ring + V ring in LDS)
-//   uncoalesced per-row loads                     16-byte coalesced tile loads, issued one tile
-//                                                 ahead, written to LDS after the compute phase
+//   uncoalesced per-row loads                     16-byte coalesced tile loads, issued ahead,
+//                                                 written to LDS after the compute phase
 //   QK^T, softmax, PV strictly one after the      software-pipelined across tiles INSIDE a wave:
 //   other                                         one straight-line block holds the QK^T MFMAs of
-//                                                 tile t+1, the exp/sum/convert of tile t, the PV
-//                                                 MFMAs of tile t and the row max of tile t+1, so
-//                                                 the matrix pipe and the vector pipe overlap
+//                                                 tile t+1, the exp/convert of tile t, the PV
+//                                                 MFMAs of tile t and the row max of tile t+1
+//   scale, max-subtraction, exp, row sum on the   Q pre-scaled by scale*log2e; -max is the MFMA's
+//   VALU per element                              initial accumulator, so P = exp2(S'); row sums
+//                                                 by MFMA (all-ones A operand)
 //
-// Work decomposition: workgroup = NW waves = 32*NW consecutive query rows of one (batch, q-head);
-// kv tiles of BK keys; linear workgroup ids are remapped so that the workgroups sharing one
-// (batch, kv-head) -- i.e. the same K/V bytes -- run on one XCD's L2.
+// Work decomposition: workgroup = NW waves x QB x 32 consecutive query rows of one (batch, q-head);
+// kv tiles of BK keys.  QB = 2 (64 rows per wave, one wave per SIMD, 512-register budget) halves the
+// LDS fragment bytes per MFMA -- every K / V fragment read from LDS feeds two MFMAs -- which is what
+// bounds the QB = 1 form (measured: per kv tile a wave waited ~700 cycles for its fragments and
+// ~470 at the barrier against ~1100 in the MFMA block; profiles/r01/).  Linear workgroup ids are
+// remapped so that the workgroups sharing one (batch, kv-head) -- the same K/V bytes -- run on one
+// XCD's L2.
 #pragma once
 #include <type_traits>
 #include "fa_common.hpp"
 
-// Timing-only ablation builds (make ABL=n OUTDIR=../lib_abl): results are WRONG by construction.
+// Timing-only ablation builds (make ABL=n OUTDIR=../lib_abl<n>): results are WRONG by construction.
 //   1 no per-interval barrier   2 no exp   3 no PV MFMAs   4 no QK^T MFMAs   5 no LDS fragment reads
 //   6 no HBM->LDS staging       7 no row-sum MFMAs          8 no row max
 #ifndef NNOP_ABL
@@ -50,16 +57,16 @@ struct FwdParams {
     const uint8_t* kpad;     // nullable, [B][KL]
     int   QL, KL, QH, KH, B;
     int   causal;
-    int   n_qblk;            // ceil(QL / (32*NW))
+    int   n_qblk;            // ceil(QL / (32*QB*NW))
     int   n_wg;              // n_qblk * QH * B
     float scale;             // 1/sqrt(E)
 };
 
 // MODE 0: plain   -- KL % BK == 0, no causal, no kpad, no pair: every logit is live
 // MODE 1: masked  -- causal and/or key padding and/or ragged KL
-// MODE 2: pair    -- masked + additive pair bias (logits kept pre-multiplied in log2 units)
-template <typename T, int E, int NW, int BK, int MODE>
-__global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
+// MODE 2: pair    -- masked + additive pair bias
+template <typename T, int E, int NW, int BK, int MODE, int QB>
+__global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const FwdParams p) {
     using frag_t = typename Elem<T>::frag;
     using KImg   = RowImg<T, E>;
     using VImg   = ColImg<T, E>;
@@ -69,9 +76,25 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
     constexpr int KS  = E / 16;                 // contraction steps of Q K^T
     constexpr int KB  = BK / 32;                // 32-key blocks per kv tile
     constexpr int EB  = (E + 31) / 32;          // 32-column blocks of O^T
+    constexpr int WROWS = 32 * QB;              // query rows per wave
     constexpr int KBYTES = KImg::bytes(BK);
     constexpr int VBYTES = VImg::bytes(BK);
     constexpr uint64_t kFull = (BK < 64) ? ((1ull << BK) - 1ull) : ~0ull;
+    constexpr int NKF = KB * KS;                // K fragments per tile
+    constexpr int NVF = EB * 2 * KB;            // V fragments per tile
+
+    // ---- feature switches, set by the register budget (256 VGPRs at QB = 1, 512 at QB = 2) --------
+    // kPipe    : software-pipelined body (two score tiles live per query block)
+    // kPrefetch: all LDS fragment reads of an interval issued up front (PFK / PFV fragments)
+    // kDeep    : HBM loads run two intervals ahead of the LDS writes (two register sets)
+    // kMfmaSum : row sums on the matrix pipe
+    constexpr bool k16 = sizeof(T) == 2;
+    constexpr bool kPipe = k16 && (E <= 64 || MODE == 0);
+    constexpr bool kPrefetch = k16 && (QB == 2 ? E <= 64 : (MODE == 0 && E <= 64));
+    constexpr int  PFK = kPrefetch ? (NKF <= 8 ? NKF : 8) : 0;
+    constexpr int  PFV = kPrefetch ? (NVF <= 8 ? NVF : 8) : 0;
+    constexpr bool kDeep = kPipe && E <= 64 && (QB == 2 || (MODE == 0 && NW == 8));
+    constexpr bool kMfmaSum = k16 && E <= 64 && (QB == 2 || MODE == 0);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -88,9 +111,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
     const int b   = bh / p.QH;
     const int qh  = bh - b * p.QH;
     const int kvh = qh / (p.QH / p.KH);                    // cld(q_head, n_q_per_kv), 0-based
-    const int q0w = qblk * (32 * NW) + wave * 32;          // first query row of this wave
-    const int qi  = q0w + r;                               // this lane's query row
-    const int qi_c = qi < p.QL ? qi : p.QL - 1;            // clamped for loads
+    const int q0w = qblk * (WROWS * NW) + wave * WROWS;    // first query row of this wave
+    int qi[QB];                                            // this lane's query row in block z
+#pragma unroll
+    for (int z = 0; z < QB; ++z) qi[z] = q0w + 32 * z + r;
 
     const T* __restrict__ qp = (const T*)p.q + ((size_t)bh * p.QL) * E;
     const char* __restrict__ kp = (const char*)((const T*)p.k + ((size_t)(b * p.KH + kvh) * p.KL) * E);
@@ -104,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
     int n_tiles = (p.KL + BK - 1) / BK;
     if constexpr (kGeneral) {
         if (p.causal) {
-            int q_last = qblk * (32 * NW) + 32 * NW - 1;
+            int q_last = qblk * (WROWS * NW) + WROWS * NW - 1;
             if (q_last > p.QL - 1) q_last = p.QL - 1;
             const int t_c = q_last / BK + 1;                   // keys <= q_last
             if (t_c < n_tiles) n_tiles = t_c;
@@ -123,10 +147,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
             if (t_m < n_tiles) n_tiles = t_m;
         }
     }
-    // tiles that are live for THIS wave (causal: up to its own diagonal)
+    // tiles that are live for THIS wave (causal: up to the diagonal of its last row)
     int n_live = n_tiles;
     if (kGeneral && p.causal) {
-        const int t_w = (q0w + 31) / BK + 1;
+        const int t_w = (q0w + WROWS - 1) / BK + 1;
         if (t_w < n_live) n_live = t_w;
     }
 
@@ -134,28 +158,23 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
     // c2 = scale * log2(e) (one rounding to T per element, once per kernel): the MFMA then produces
     // logits in log2 units and P = exp2(S') needs no per-element multiply.
     const float c2 = p.scale * kLog2e;
-    frag_t qf[KS];
-    {
-        const T* qrow = qp + (size_t)qi_c * E;
+    frag_t qf[QB][KS];
+#pragma unroll
+    for (int z = 0; z < QB; ++z) {
+        const int qc = qi[z] < p.QL ? qi[z] : p.QL - 1;    // clamped for loads
+        const T* qrow = qp + (size_t)qc * E;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const frag_t raw = *reinterpret_cast<const frag_t*>(qrow + 16 * ks + 8 * h);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qf[ks][j] = from_f32<T>(to_f32(raw[j]) * c2);
+            for (int j = 0; j < 8; ++j) qf[z][ks][j] = from_f32<T>(to_f32(raw[j]) * c2);
         }
     }
 
-    // ---- staging (K runs ONE TILE AHEAD of V) ---------------------------------------------
+    // ---- staging (pipelined: K runs ONE TILE AHEAD of V) -----------------------------------
     //   interval t (between two barriers) reads K(t+1) and V(t); at its end K(t+2) replaces K(t)
-    //   and V(t+1) replaces V(t-1): a K ring of 2 and a V ring of 2.  The HBM/L2 loads run one
-    //   interval further ahead than the LDS writes (two register sets): K(t+3), V(t+2) are requested
-    //   at the top of interval t and written at the end of interval t+1, so a load has two intervals
-    //   to land (one interval alone does not cover the L2 latency under load).
-    // kPipe: software-pipelined body (two score tiles live).  Needs the registers: 16-bit types,
-    // E <= 64 in every mode, E = 128 in plain mode only.  Everything else (fp32, whose MFMAs are 16x
-    // longer and already dominate; E = 128 masked) runs one tile per interval: X(t) then Y(t).
-    constexpr bool kPipe = sizeof(T) == 2 && (E <= 64 || MODE == 0);
-    constexpr bool kDeep = kPipe && MODE == 0 && E <= 64 && NW == 8;
+    //   and V(t+1) replaces V(t-1): a K ring of 2 and a V ring of 2.  With kDeep the HBM/L2 loads run
+    //   one interval further ahead than the LDS writes (two register sets).
     Stager<T, E, BK, NT> sk0, sv0, sk1, sv1;
     auto stage = [&](Stager<T, E, BK, NT>& st, const char* base, int t) {
         if constexpr (kGeneral) st.load(base + (size_t)t * ((size_t)BK * E * sizeof(T)), p.KL - t * BK, tid);
@@ -164,11 +183,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
 
     const int vbase = VImg::lane_base(lane);
 
-    f32x16 oacc[EB];
+    f32x16 oacc[QB][EB];
 #pragma unroll
-    for (int eb = 0; eb < EB; ++eb)
+    for (int z = 0; z < QB; ++z)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[eb][i] = 0.f;
+        for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[z][eb][i] = 0.f;
+
     // Deferred-max online softmax.  m2 is the exponent REFERENCE (log2 units, per query row, shared
     // by lanes r and r+32); -m2 is the INITIAL ACCUMULATOR of the QK^T MFMA chain (`cinit`, 16 equal
     // registers), so the accumulators hold S' = S - m2 and P = exp2(S') costs one v_exp and nothing
@@ -177,46 +199,42 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
     // the row's first visible key.  mt is the TRUE running row max, kept because the residual
     // contract wants it (ms = row max, src/attention.jl:128).
     constexpr float kThr = 8.0f;
-    constexpr bool kMfmaSum = sizeof(T) == 2 && MODE == 0 && E <= 64;   // row sums on the matrix pipe (all-ones A operand)
-    float m2 = 0.f;
-    float mt = -INFINITY;
-    float lsum = 0.f;          // VALU row sum over THIS lane's keys (fp32 path; halves added at the end)
-    f32x16 cinit, lacc;
+    float m2[QB], mt[QB], lsum[QB];
+    f32x16 cinit[QB], lacc[QB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { cinit[i] = 0.f; lacc[i] = 0.f; }
+    for (int z = 0; z < QB; ++z) {
+        m2[z] = 0.f; mt[z] = -INFINITY; lsum[z] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { cinit[z][i] = 0.f; lacc[z][i] = 0.f; }
+    }
     frag_t ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = from_f32<T>(1.0f);
 
-    // ---- X(t): S^T = K Q^T for kv tile t (MFMA) ---------------------------------------------
-    // LDS fragment reads are issued EARLY (kf_load / vf_load at the top of an interval, pinned by a
-    // sched_barrier) and consumed late: one LDS round trip (~100+ cycles under load) in front of
-    // every MFMA was the dominant stall of the un-prefetched loop.  fp32 keeps fragments in flight
-    // only one MFMA group ahead (its MFMAs are 16x longer, and its fragments 2x the registers).
-    constexpr int NKF = KB * KS;                       // K fragments per tile
-    constexpr int NVF = EB * 2 * KB;                   // V fragments per tile
-    // (register budget: only the plain variants have room; E=128 prefetches half as many)
-    constexpr bool kPrefetch = sizeof(T) == 2 && MODE == 0 && E <= 64;
-    constexpr int kPfMax = 8;
-    constexpr int PFK = kPrefetch ? (NKF <= kPfMax ? NKF : kPfMax) : 0;   // fragments prefetched to registers
-    constexpr int PFV = kPrefetch ? (NVF <= kPfMax ? NVF : kPfMax) : 0;
+    // ---- LDS fragment reads.  With kPrefetch they are issued EARLY (top of an interval, pinned by a
+    // sched_barrier) and consumed late; every fragment is shared by the wave's QB query blocks.
     auto kf_load = [&](const char* kimg, frag_t (&kf)[PFK > 0 ? PFK : 1]) {
 #pragma unroll
+        for (int f = 0; f < PFK; ++f) {
 #if NNOP_ABL != 5
-        for (int f = 0; f < PFK; ++f) kf[f] = KImg::read_row_frag(kimg, 32 * (f / KS) + r, h, f % KS);
+            kf[f] = KImg::read_row_frag(kimg, 32 * (f / KS) + r, h, f % KS);
 #else
-        for (int f = 0; f < PFK; ++f) kf[f] = qf[f % KS];
+            kf[f] = qf[0][f % KS];
 #endif
+        }
     };
     auto vf_load = [&](const char* vimg, frag_t (&vf)[PFV > 0 ? PFV : 1]) {
 #pragma unroll
+        for (int f = 0; f < PFV; ++f) {
 #if NNOP_ABL != 5
-        for (int f = 0; f < PFV; ++f) vf[f] = VImg::read_col_frag(vimg + vbase, f % (2 * KB), f / (2 * KB));
+            vf[f] = VImg::read_col_frag(vimg + vbase, f % (2 * KB), f / (2 * KB));
 #else
-        for (int f = 0; f < PFV; ++f) vf[f] = qf[f % KS];
+            vf[f] = qf[0][f % KS];
 #endif
+        }
     };
-    auto qk_tile = [&](const char* kimg, const frag_t (&kf)[PFK > 0 ? PFK : 1], f32x16 (&s)[KB]) {
+    // ---- X(t): S'^T = K Q^T - m2 for kv tile t, all query blocks (MFMA) ----------------------
+    auto qk_tile = [&](const char* kimg, const frag_t (&kf)[PFK > 0 ? PFK : 1], f32x16 (&s)[QB][KB]) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
@@ -225,12 +243,15 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
                 frag_t a;
                 if (f < PFK) a = kf[f < PFK ? f : 0];
                 else a = KImg::read_row_frag(kimg, 32 * kb + r, h, ks);
+#pragma unroll
+                for (int z = 0; z < QB; ++z) {
 #if NNOP_ABL != 4
-                s[kb] = mma16<T>(a, qf[ks], ks == 0 ? cinit : s[kb]);     // S' = K Q^T - m2
+                    s[z][kb] = mma16<T>(a, qf[z][ks], ks == 0 ? cinit[z] : s[z][kb]);
 #else
-                if (ks == 0) s[kb] = cinit;
-                s[kb][ks] += (float)a[0];
+                    if (ks == 0) s[z][kb] = cinit[z];
+                    s[z][kb][ks] += (float)a[0];
 #endif
+                }
             }
         }
     };
@@ -251,9 +272,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
     auto tile_needs_mask = [&](int t, uint64_t valid) {
         return kGeneral && (valid != kFull || (p.causal && t * BK + BK - 1 > q0w));
     };
-    // mask (-> -inf) / bias tile t in place and return max(S') over the row (both halves): the
-    // row max relative to the reference the tile was computed against.
-    auto finish_x = [&](auto masked, f32x16 (&s)[KB], int t, uint64_t valid) -> float {
+    // mask (-> -inf) / bias tile t of query block z in place and return max(S') over the row (both
+    // halves): the row max relative to the reference the tile was computed against.
+    auto finish_x = [&](auto masked, int z, f32x16 (&s)[KB], int t, uint64_t valid) -> float {
         constexpr bool MASKED = decltype(masked)::value;
         const int k0 = t * BK;
         float mxp[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // 4 independent chains
@@ -261,7 +282,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const uint32_t w = (uint32_t)(valid >> (32 * kb + 4 * h));
-                const int lim = qi - k0 - 32 * kb - 4 * h;                  // causal: local row <= lim
+                const int lim = qi[z] - k0 - 32 * kb - 4 * h;               // causal: local row <= lim
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int lr = (i & 3) + 8 * (i >> 2);
@@ -273,8 +294,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
                     float x = s[kb][i];
                     if constexpr (kPair) {
                         const int key = k0 + 32 * kb + lr + 4 * h;
-                        if (ok && qi < p.QL && key < p.KL) {
-                            const size_t po = (((size_t)b * p.KL + key) * p.QL + qi) * p.QH + qh;
+                        if (ok && qi[z] < p.QL && key < p.KL) {
+                            const size_t po = (((size_t)b * p.KL + key) * p.QL + qi[z]) * p.QH + qh;
                             x += to_f32(((const T*)p.pair)[po]) * kLog2e;
                         }
                     }
@@ -289,74 +310,102 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
                 for (int i = 0; i < 16; i += 2)
                     mxp[(i >> 1) & 3] = fmaxf(fmaxf(mxp[(i >> 1) & 3], s[kb][i]), s[kb][i + 1]);
         }
+#if NNOP_ABL == 8
+        return s[0][0];
+#endif
         return half_swap_max(fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3])));
     };
+    auto finish_all = [&](auto masked, f32x16 (&s)[QB][KB], float (&mx)[QB], int t, uint64_t valid) {
+#pragma unroll
+        for (int z = 0; z < QB; ++z) mx[z] = finish_x(masked, z, s[z], t, valid);
+    };
     // Y(t): exp / convert / O^T += V^T P^T (+ row sums) for tile t, one 16-key step at a time so
-    // that the exps of step kk+1 sit beside the MFMAs of step kk.
-    auto softmax_pv = [&](f32x16 (&s)[KB], const char* vimg, const frag_t (&vfp)[PFV > 0 ? PFV : 1]) {
-        float lp[4] = {0.f, 0.f, 0.f, 0.f};                                  // 4 independent chains
+    // that the exps of step kk+1 sit beside the MFMAs of step kk; V fragments shared by the blocks.
+    auto softmax_pv = [&](f32x16 (&s)[QB][KB], const char* vimg, const frag_t (&vfp)[PFV > 0 ? PFV : 1]) {
+        float lp[QB][4];
+#pragma unroll
+        for (int z = 0; z < QB; ++z)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lp[z][c] = 0.f;
         const char* vb = vimg + vbase;
 #pragma unroll
         for (int kk = 0; kk < 2 * KB; ++kk) {
             const int kb = kk >> 1, i0 = 8 * (kk & 1);
+            frag_t pf[QB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int z = 0; z < QB; ++z) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
 #if NNOP_ABL != 2
-                s[kb][i0 + j] = fast_exp2(s[kb][i0 + j]);
+                    s[z][kb][i0 + j] = fast_exp2(s[z][kb][i0 + j]);
 #endif
-                if constexpr (!kMfmaSum) lp[j & 3] += s[kb][i0 + j];
-            }
-            // P^T comes straight from the S^T accumulators (acc_frag): no LDS, no lane movement
-            const frag_t pf = (kk & 1) ? acc_frag<T, 1>(s[kb]) : acc_frag<T, 0>(s[kb]);
-            // row sums: ones[32 x 16] * P^T -> every accumulator row holds sum_k P^T[k][query]
+                    if constexpr (!kMfmaSum) lp[z][j & 3] += s[z][kb][i0 + j];
+                }
+                // P^T comes straight from the S^T accumulators (acc_frag): no LDS, no lane movement
+                pf[z] = (kk & 1) ? acc_frag<T, 1>(s[z][kb]) : acc_frag<T, 0>(s[z][kb]);
+                // row sums: ones[32 x 16] * P^T -> every accumulator row holds sum_k P^T[k][query]
 #if NNOP_ABL != 7
-            if constexpr (kMfmaSum) lacc = mma16<T>(ones, pf, lacc);
-#else
-            lacc[0] += (float)pf[0];
+                if constexpr (kMfmaSum) lacc[z] = mma16<T>(ones, pf[z], lacc[z]);
 #endif
+            }
 #pragma unroll
             for (int eb = 0; eb < EB; ++eb) {
                 const int f = eb * 2 * KB + kk;
                 frag_t vf;
                 if (f < PFV) vf = vfp[f < PFV ? f : 0];
                 else vf = VImg::read_col_frag(vb, kk, eb);
+#pragma unroll
+                for (int z = 0; z < QB; ++z) {
 #if NNOP_ABL != 3
-                oacc[eb] = mma16<T>(vf, pf, oacc[eb]);
+                    oacc[z][eb] = mma16<T>(vf, pf[z], oacc[z][eb]);
 #else
-                oacc[eb][kk] += (float)vf[0] * (float)pf[0];
+                    oacc[z][eb][kk] += (float)vf[0] * (float)pf[z][0];
 #endif
+                }
             }
         }
-        if constexpr (!kMfmaSum) lsum += (lp[0] + lp[1]) + (lp[2] + lp[3]);
+        if constexpr (!kMfmaSum) {
+#pragma unroll
+            for (int z = 0; z < QB; ++z) lsum[z] += (lp[z][0] + lp[z][1]) + (lp[z][2] + lp[z][3]);
+        }
     };
     // Top of interval t: `sc` holds S'(t) relative to the current reference m2 and `mxr` its row
     // max.  Rare path: some row's max outgrew the reference by > kThr, or a row meets its first
     // visible key -> move the reference.  Everything at the old reference is shifted exactly once:
     // O, l (accumulated so far), the not-yet-exponentiated S'(t), and the MFMA initial accumulator.
-    auto rescale = [&](f32x16 (&sc)[KB], float mxr) {
-        const bool first = (mt == -INFINITY) && (mxr != -INFINITY);
-        mt = fmaxf(mt, m2 + mxr);
-        if (__any(mxr > kThr || first)) {
-            const float d = first ? mxr : fmaxf(mxr, 0.f);       // reference moves by d (log2 units)
-            const float dd = (d == -INFINITY) ? 0.f : d;
-            const float alpha = first ? 1.f : fast_exp2(-dd);     // nothing accumulated before `first`
+    auto rescale = [&](f32x16 (&sc)[QB][KB], const float (&mxr)[QB]) {
+        bool any = false;
+        bool first[QB];
 #pragma unroll
-            for (int eb = 0; eb < EB; ++eb)
+        for (int z = 0; z < QB; ++z) {
+            first[z] = (mt[z] == -INFINITY) && (mxr[z] != -INFINITY);
+            mt[z] = fmaxf(mt[z], m2[z] + mxr[z]);
+            any = any || (mxr[z] > kThr) || first[z];
+        }
+        if (__any(any)) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[eb][i] *= alpha;
-            if constexpr (kMfmaSum) {
+            for (int z = 0; z < QB; ++z) {
+                const float d = first[z] ? mxr[z] : (mxr[z] > kThr ? mxr[z] : 0.f);
+                const float dd = (d == -INFINITY) ? 0.f : d;          // reference moves by dd (log2 units)
+                const float alpha = first[z] ? 1.f : fast_exp2(-dd);   // nothing accumulated before `first`
 #pragma unroll
-                for (int i = 0; i < 16; ++i) lacc[i] *= alpha;
-            } else {
-                lsum *= alpha;
+                for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[z][eb][i] *= alpha;
+                if constexpr (kMfmaSum) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) lacc[z][i] *= alpha;
+                } else {
+                    lsum[z] *= alpha;
+                }
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sc[z][kb][i] -= dd;
+                m2[z] += dd;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cinit[z][i] = -m2[z];
             }
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sc[kb][i] -= dd;
-            m2 += dd;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cinit[i] = -m2;
         }
     };
 
@@ -370,21 +419,25 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
             sv0.template write<VImg>(vring, tid);
         }
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) landed(qf[ks]);
+        for (int z = 0; z < QB; ++z)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) landed(qf[z][ks]);
         __syncthreads();
         for (int t = 0; t < n_tiles; ++t) {
             const bool more1 = t + 1 < n_tiles;
             if (more1) { stage(sk0, kp, t + 1); stage(sv0, vp, t + 1); }
             if (t < n_live) {
-                f32x16 sc[KB];
-                frag_t nokf[1], novf[1];
-                qk_tile(kring + (t & 1) * KBYTES, nokf, sc);
+                f32x16 sc[QB][KB];
+                float mxr[QB];
+                frag_t kfr[PFK > 0 ? PFK : 1], vfr[PFV > 0 ? PFV : 1];
+                kf_load(kring + (t & 1) * KBYTES, kfr);
+                vf_load(vring + (t & 1) * VBYTES, vfr);
+                qk_tile(kring + (t & 1) * KBYTES, kfr, sc);
                 const uint64_t vt = tile_valid(t);
-                float mxr;
-                if (tile_needs_mask(t, vt)) mxr = finish_x(std::true_type{}, sc, t, vt);
-                else mxr = finish_x(std::false_type{}, sc, t, vt);
+                if (tile_needs_mask(t, vt)) finish_all(std::true_type{}, sc, mxr, t, vt);
+                else finish_all(std::false_type{}, sc, mxr, t, vt);
                 rescale(sc, mxr);
-                softmax_pv(sc, vring + (t & 1) * VBYTES, novf);
+                softmax_pv(sc, vring + (t & 1) * VBYTES, vfr);
             }
             if (more1) {
                 sk0.template write<KImg>(kring + ((t + 1) & 1) * KBYTES, tid);
@@ -393,148 +446,150 @@ __global__ __launch_bounds__(NW * 64, 2) void fa_fwd_kernel(const FwdParams p) {
             __syncthreads();
         }
     } else {
-    // ---- prologue: K(0), V(0), K(1) -> LDS; K(2), V(1) -> register set 1; X(0) ------------------
-    f32x16 sa[KB], sb[KB];
-    float mxa = -INFINITY, mxb = -INFINITY;
-    if (n_tiles > 0) {
-        stage(sk0, kp, 0);
-        stage(sv0, vp, 0);
-        if (n_tiles > 1) stage(sk1, kp, 1);
-        sk0.template write<KImg>(kring, tid);
-        sv0.template write<VImg>(vring, tid);
-        if (n_tiles > 1) {
-            sk1.template write<KImg>(kring + KBYTES, tid);
-            if constexpr (kDeep) stage(sv1, vp, 1);
-        }
-        if constexpr (kDeep) {
-            if (n_tiles > 2) stage(sk1, kp, 2);
-        }
-    }
+        // ---- prologue: K(0), V(0), K(1) -> LDS; (kDeep: K(2), V(1) -> register set 1); X(0) ---------
+        f32x16 sa[QB][KB], sb[QB][KB];
+        float mxa[QB], mxb[QB];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) landed(qf[ks]);
-    __syncthreads();
-    if (n_live > 0) {
-        frag_t kf0[PFK > 0 ? PFK : 1];
-        kf_load(kring, kf0);
-        qk_tile(kring, kf0, sa);
-        const uint64_t v0 = tile_valid(0);
-        if (tile_needs_mask(0, v0)) mxa = finish_x(std::true_type{}, sa, 0, v0);
-        else mxa = finish_x(std::false_type{}, sa, 0, v0);
-    }
-    __syncthreads();      // every wave has read K(0) before interval 0 ends by overwriting it
-
-    // one interval: Y(t) on `sc` (row max `mxc` known) together with X(t+1) into `sn` / `mxn`.
-    // (skl, svl): register set loaded this interval; (skw, svw): set written at its end.
-    auto interval = [&](int t, f32x16 (&sc)[KB], float mxc, f32x16 (&sn)[KB], float& mxn,
-                        Stager<T, E, BK, NT>& skl, Stager<T, E, BK, NT>& svl,
-                        Stager<T, E, BK, NT>& skw, Stager<T, E, BK, NT>& svw) {
-        const bool more1 = t + 1 < n_tiles, more2 = t + 2 < n_tiles, more3 = t + 3 < n_tiles;
-#if NNOP_ABL != 6
-        if constexpr (kDeep) {
-            if (more3) stage(skl, kp, t + 3);
-            if (more2) stage(svl, vp, t + 2);
-        } else {
-            if (more2) stage(skw, kp, t + 2);
-            if (more1) stage(svw, vp, t + 1);
-        }
-#endif
-        const char* knext = kring + ((t + 1) & 1) * KBYTES;
-        const char* vcur = vring + (t & 1) * VBYTES;
-        frag_t kfr[PFK > 0 ? PFK : 1], vfr[PFV > 0 ? PFV : 1];
-        if constexpr (!kGeneral) {
-            rescale(sc, mxc);
-            // ONE basic block: LDS fragment reads first, then QK^T(t+1) MFMAs | exp, convert (t)
-            // | PV(t) MFMAs | row max (t+1).  Past the last tile the K ring holds a stale tile: the
-            // result is never used.
-            kf_load(knext, kfr);
-            vf_load(vcur, vfr);
-            __builtin_amdgcn_sched_barrier(0);
-            qk_tile(knext, kfr, sn);
-            softmax_pv(sc, vcur, vfr);
-#if NNOP_ABL != 8
-            mxn = finish_x(std::false_type{}, sn, t + 1, kFull);
-#else
-            mxn = sn[0][0];
-#endif
-        } else {
-            if (t < n_live) {
-                rescale(sc, mxc);
-                if (t + 1 < n_live) {
-                    const uint64_t vn = tile_valid(t + 1);
-                    const bool nm = tile_needs_mask(t + 1, vn);
-                    kf_load(knext, kfr);
-                    vf_load(vcur, vfr);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (nm) {
-                        qk_tile(knext, kfr, sn);
-                        softmax_pv(sc, vcur, vfr);
-                        mxn = finish_x(std::true_type{}, sn, t + 1, vn);
-                    } else {
-                        qk_tile(knext, kfr, sn);
-                        softmax_pv(sc, vcur, vfr);
-                        mxn = finish_x(std::false_type{}, sn, t + 1, vn);
-                    }
-                } else {
-                    vf_load(vcur, vfr);
-                    softmax_pv(sc, vcur, vfr);
-                }
+        for (int z = 0; z < QB; ++z) { mxa[z] = -INFINITY; mxb[z] = -INFINITY; }
+        if (n_tiles > 0) {
+            stage(sk0, kp, 0);
+            stage(sv0, vp, 0);
+            if (n_tiles > 1) stage(sk1, kp, 1);
+            sk0.template write<KImg>(kring, tid);
+            sv0.template write<VImg>(vring, tid);
+            if (n_tiles > 1) {
+                sk1.template write<KImg>(kring + KBYTES, tid);
+                if constexpr (kDeep) stage(sv1, vp, 1);
+            }
+            if constexpr (kDeep) {
+                if (n_tiles > 2) stage(sk1, kp, 2);
             }
         }
+#pragma unroll
+        for (int z = 0; z < QB; ++z)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) landed(qf[z][ks]);
+        __syncthreads();
+        if (n_live > 0) {
+            frag_t kf0[PFK > 0 ? PFK : 1];
+            kf_load(kring, kf0);
+            qk_tile(kring, kf0, sa);
+            const uint64_t v0 = tile_valid(0);
+            if (tile_needs_mask(0, v0)) finish_all(std::true_type{}, sa, mxa, 0, v0);
+            else finish_all(std::false_type{}, sa, mxa, 0, v0);
+        }
+        __syncthreads();      // every wave has read K(0) before interval 0 ends by overwriting it
+
+        // one interval: Y(t) on `sc` (row max `mxc` known) together with X(t+1) into `sn` / `mxn`.
+        // (skl, svl): register set loaded this interval; (skw, svw): set written at its end.
+        auto interval = [&](int t, f32x16 (&sc)[QB][KB], const float (&mxc)[QB], f32x16 (&sn)[QB][KB],
+                            float (&mxn)[QB], Stager<T, E, BK, NT>& skl, Stager<T, E, BK, NT>& svl,
+                            Stager<T, E, BK, NT>& skw, Stager<T, E, BK, NT>& svw) {
+            const bool more1 = t + 1 < n_tiles, more2 = t + 2 < n_tiles, more3 = t + 3 < n_tiles;
 #if NNOP_ABL != 6
-        if (more2) skw.template write<KImg>(kring + (t & 1) * KBYTES, tid);
-        if (more1) svw.template write<VImg>(vring + ((t + 1) & 1) * VBYTES, tid);
+            if constexpr (kDeep) {
+                if (more3) stage(skl, kp, t + 3);
+                if (more2) stage(svl, vp, t + 2);
+            } else {
+                if (more2) stage(skw, kp, t + 2);
+                if (more1) stage(svw, vp, t + 1);
+            }
+#endif
+            const char* knext = kring + ((t + 1) & 1) * KBYTES;
+            const char* vcur = vring + (t & 1) * VBYTES;
+            frag_t kfr[PFK > 0 ? PFK : 1], vfr[PFV > 0 ? PFV : 1];
+            if constexpr (!kGeneral) {
+                rescale(sc, mxc);
+                // ONE basic block: LDS fragment reads first, then QK^T(t+1) MFMAs | exp, convert (t)
+                // | PV(t) MFMAs | row max (t+1).  Past the last tile the K ring holds a stale tile:
+                // the result is never used.
+                kf_load(knext, kfr);
+                vf_load(vcur, vfr);
+                __builtin_amdgcn_sched_barrier(0);
+                qk_tile(knext, kfr, sn);
+                softmax_pv(sc, vcur, vfr);
+                finish_all(std::false_type{}, sn, mxn, t + 1, kFull);
+            } else {
+                if (t < n_live) {
+                    rescale(sc, mxc);
+                    if (t + 1 < n_live) {
+                        const uint64_t vn = tile_valid(t + 1);
+                        const bool nm = tile_needs_mask(t + 1, vn);
+                        kf_load(knext, kfr);
+                        vf_load(vcur, vfr);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (nm) {
+                            qk_tile(knext, kfr, sn);
+                            softmax_pv(sc, vcur, vfr);
+                            finish_all(std::true_type{}, sn, mxn, t + 1, vn);
+                        } else {
+                            qk_tile(knext, kfr, sn);
+                            softmax_pv(sc, vcur, vfr);
+                            finish_all(std::false_type{}, sn, mxn, t + 1, vn);
+                        }
+                    } else {
+                        vf_load(vcur, vfr);
+                        softmax_pv(sc, vcur, vfr);
+                    }
+                }
+            }
+#if NNOP_ABL != 6
+            if (more2) skw.template write<KImg>(kring + (t & 1) * KBYTES, tid);
+            if (more1) svw.template write<VImg>(vring + ((t + 1) & 1) * VBYTES, tid);
 #endif
 #if NNOP_ABL != 1
-        __syncthreads();
+            __syncthreads();
 #endif
-    };
+        };
 
-    for (int t = 0; t < n_tiles; t += 2) {
-        if constexpr (kDeep) {
-            interval(t, sa, mxa, sb, mxb, sk0, sv0, sk1, sv1);
-            if (t + 1 < n_tiles) interval(t + 1, sb, mxb, sa, mxa, sk1, sv1, sk0, sv0);
-        } else {        // one register set: loaded at the top of an interval, written at its end
-            interval(t, sa, mxa, sb, mxb, sk0, sv0, sk0, sv0);
-            if (t + 1 < n_tiles) interval(t + 1, sb, mxb, sa, mxa, sk0, sv0, sk0, sv0);
+        for (int t = 0; t < n_tiles; t += 2) {
+            if constexpr (kDeep) {
+                interval(t, sa, mxa, sb, mxb, sk0, sv0, sk1, sv1);
+                if (t + 1 < n_tiles) interval(t + 1, sb, mxb, sa, mxa, sk1, sv1, sk0, sv0);
+            } else {        // one register set: loaded at the top of an interval, written at its end
+                interval(t, sa, mxa, sb, mxb, sk0, sv0, sk0, sv0);
+                if (t + 1 < n_tiles) interval(t + 1, sb, mxb, sa, mxa, sk0, sv0, sk0, sv0);
+            }
         }
-    }
-
     }   // kPipe
 
     // ---- epilogue: normalise, store o, ms, ls -----------------------------------------------
-    const float ltot = kMfmaSum ? lacc[0] : half_swap_sum(lsum);
-    const float inv = 1.0f / ltot;                         // ltot == 0 (no visible key) -> NaN rows,
+#pragma unroll
+    for (int z = 0; z < QB; ++z) {
+        const float ltot = kMfmaSum ? lacc[z][0] : half_swap_sum(lsum[z]);
+        const float inv = 1.0f / ltot;                     // ltot == 0 (no visible key) -> NaN rows,
                                                            // as the naive formula gives
-    if (qi < p.QL) {
-        T* orow = (T*)p.o + ((size_t)bh * p.QL + qi) * E;
+        if (qi[z] < p.QL) {
+            T* orow = (T*)p.o + ((size_t)bh * p.QL + qi[z]) * E;
 #pragma unroll
-        for (int eb = 0; eb < EB; ++eb)
+            for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int e = 32 * eb + 8 * g + 4 * h;
-                if (e < E) {
-                    f32x4 w = {oacc[eb][4 * g] * inv, oacc[eb][4 * g + 1] * inv,
-                               oacc[eb][4 * g + 2] * inv, oacc[eb][4 * g + 3] * inv};
-                    if constexpr (sizeof(T) == 4) {
-                        *reinterpret_cast<f32x4*>(orow + e) = w;
-                    } else {
-                        typedef T t4 __attribute__((ext_vector_type(4)));
-                        *reinterpret_cast<t4*>(orow + e) = __builtin_convertvector(w, t4);
+                for (int g = 0; g < 4; ++g) {
+                    const int e = 32 * eb + 8 * g + 4 * h;
+                    if (e < E) {
+                        f32x4 w = {oacc[z][eb][4 * g] * inv, oacc[z][eb][4 * g + 1] * inv,
+                                   oacc[z][eb][4 * g + 2] * inv, oacc[z][eb][4 * g + 3] * inv};
+                        if constexpr (sizeof(T) == 4) {
+                            *reinterpret_cast<f32x4*>(orow + e) = w;
+                        } else {
+                            typedef T t4 __attribute__((ext_vector_type(4)));
+                            *reinterpret_cast<t4*>(orow + e) = __builtin_convertvector(w, t4);
+                        }
                     }
                 }
+            if (h == 0) {
+                // Residual contract (src/attention.jl:128-129): ms = row max (natural-log units),
+                // ls = sum exp(s - ms), both in T.  ms is rounded to T first and ls is expressed
+                // relative to the ROUNDED ms, so the pair stays self-consistent in 16-bit types.
+                const size_t so = (size_t)bh * p.QL + qi[z];
+                const float m_nat = mt[z] * kLn2;
+                const T m_t = from_f32<T>(m_nat);
+                const float m_back = to_f32(m_t);
+                float l_out = ltot;                        // sum exp2(x - m2) -> sum exp(s - ms)
+                if (mt[z] != -INFINITY) l_out = ltot * fast_exp2(m2[z] - m_back * kLog2e);
+                ((T*)p.ms)[so] = m_t;
+                ((T*)p.ls)[so] = from_f32<T>(l_out);
             }
-        if (h == 0) {
-            // Residual contract (src/attention.jl:128-129): ms = row max (natural-log units),
-            // ls = sum exp(s - ms), both in T.  ms is rounded to T first and ls is expressed
-            // relative to the ROUNDED ms, so the pair stays self-consistent in 16-bit types.
-            const size_t so = (size_t)bh * p.QL + qi;
-            const float m_nat = mt * kLn2;
-            const T m_t = from_f32<T>(m_nat);
-            const float m_back = to_f32(m_t);
-            float l_out = ltot;                            // sum exp2(x - m2) -> sum exp(s - ms)
-            if (mt != -INFINITY) l_out = ltot * fast_exp2(m2 - m_back * kLog2e);
-            ((T*)p.ms)[so] = m_t;
-            ((T*)p.ls)[so] = from_f32<T>(l_out);
         }
     }
 }

@@ -12,14 +12,14 @@
 
 namespace nnop {
 
-template <typename T, int E, int NW, int MODE>
+template <typename T, int E, int NW, int MODE, int QB>
 static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
-    // 64-key tiles, except where the masked body would not fit 256 VGPRs (E = 128) and fp32 E = 128
-    // (LDS: 2 x (K + V) x 64 keys x 512 B = 128 KiB would leave one workgroup per CU)
-    constexpr int BK = (E >= 128 && (MODE != 0 || sizeof(T) == 4)) ? 32 : 64;
+    // 64-key tiles, except where the masked body would not fit 256 VGPRs (E = 128, QB = 1) and fp32
+    // E = 128 (LDS: 2 x (K + V) x 64 keys x 512 B = 128 KiB would leave one workgroup per CU)
+    constexpr int BK = (E >= 128 && ((MODE != 0 && QB == 1) || sizeof(T) == 4)) ? 32 : 64;
     constexpr int lds = fa_fwd_lds_bytes<T, E, BK>();
     static_assert(lds <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
-    auto kern = fa_fwd_kernel<T, E, NW, BK, MODE>;
+    auto kern = fa_fwd_kernel<T, E, NW, BK, MODE, QB>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             (void)hipGetLastError();
@@ -31,7 +31,8 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     p.q = a.q; p.k = a.k; p.v = a.v; p.pair = a.pair; p.kpad = a.kpad;
     p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
     p.causal = d.causal ? 1 : 0;
-    p.n_qblk = (d.ql + 32 * NW - 1) / (32 * NW);
+    constexpr int rows = 32 * QB * NW;
+    p.n_qblk = (d.ql + rows - 1) / rows;
     const long long n_wg = (long long)p.n_qblk * d.qh * d.batch;
     if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.n_wg = (int)n_wg;
@@ -41,25 +42,34 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
+template <typename T, int E, int NW, int QB>
+static int launch_fwd_mode(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s, int mode) {
+    if (mode == 0) return launch_fwd_cfg<T, E, NW, 0, QB>(d, a, s);
+    if (mode == 1) return launch_fwd_cfg<T, E, NW, 1, QB>(d, a, s);
+    return launch_fwd_cfg<T, E, NW, 2, QB>(d, a, s);
+}
+
 template <typename T, int E>
 static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
     // 0 = plain (every logit live), 1 = masked (causal / key padding / ragged KL), 2 = + pair bias
     const int mode = a.pair ? 2 : ((d.causal || a.kpad || (d.kl % 64) != 0) ? 1 : 0);
-    // waves per workgroup: 8 (256 query rows) when that still yields >= one workgroup per CU,
-    // else 4 (128 rows) so that small problems spread over more CUs.
-    int nw = 8;
-    const long long wg8 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
-    if (wg8 < 256 || d.ql <= 128) nw = 4;
-    if (E >= 128 && mode != 0) nw = 4;      // the masked E=128 body needs > 256 VGPRs at 2 waves per SIMD
+    // Workgroup shape: 8 waves x 32 rows (256-row workgroups) when that still yields >= one
+    // workgroup per CU, else 4 waves x 32 rows so that small problems spread over more CUs.
+    const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
+    int nw = 8, qb = 1;
+    if (wg256 < 256 || d.ql <= 128) nw = 4;
+    if (E >= 128 && mode != 0) nw = 4;               // the masked E=128 body: 4 waves per workgroup
     nw = env_int("NNOP_FWD_NW", nw);
-    if (nw == 8) {
-        if (mode == 0) return launch_fwd_cfg<T, E, 8, 0>(d, a, s);
-        if (mode == 1) return launch_fwd_cfg<T, E, 8, 1>(d, a, s);
-        return launch_fwd_cfg<T, E, 8, 2>(d, a, s);
+    // QB = 2 (4 waves x 64 rows, one wave per SIMD) is EXPERIMENTAL and opt-in: it halves the LDS
+    // fragment traffic per MFMA, but hipcc's allocator then shuttles the score tiles between AGPRs
+    // and VGPRs (~440 v_accvgpr moves per kv tile) and it runs 1.3x SLOWER than QB = 1 (measured,
+    // DESIGN.md section 6).  Plain mode, E <= 64 only.
+    qb = env_int("NNOP_FWD_QB", qb);
+    if constexpr (sizeof(T) == 2 && E <= 64) {
+        if (qb == 2 && mode == 0) return launch_fwd_cfg<T, E, 4, 0, 2>(d, a, s);
     }
-    if (mode == 0) return launch_fwd_cfg<T, E, 4, 0>(d, a, s);
-    if (mode == 1) return launch_fwd_cfg<T, E, 4, 1>(d, a, s);
-    return launch_fwd_cfg<T, E, 4, 2>(d, a, s);
+    if (nw == 8) return launch_fwd_mode<T, E, 8, 1>(d, a, s, mode);
+    return launch_fwd_mode<T, E, 4, 1>(d, a, s, mode);
 }
 
 template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
