@@ -39,7 +39,10 @@ CONFIGS = {
     "c2": ("bf16", 64, 4096, 4, 4, 4, False),           # headline (BASELINE.json configs[1])
     "c1gpu": ("f32", 64, 4096, 4, 4, 4, False),         # fp32 twin of configs[0] on the GPU
     "c3": ("bf16", 128, 8192, 32, 32, 8, True),          # configs[2]
+    "c4": ("f16", 128, 4096, 32, 8, 16, False),          # configs[3]: GQA 32/8, variable sequence length
 }
+# C4 lengths: numpy.random.default_rng(0).integers(1024, 4097, size=16)
+C4_LENS = [3637, 2981, 2594, 1853, 1969, 1149, 1255, 1074, 1562, 3523, 3019, 3828, 2571, 2888, 4007, 3265]
 
 
 def parse():
@@ -126,8 +129,13 @@ def main():
     ms = torch.empty(B, QH, L, dtype=dt, device=dev)
     ls = torch.empty_like(ms)
 
+    kpad, kv_lens = None, None
+    if args.config == "c4":
+        kv_lens = C4_LENS
+        kpad = (torch.arange(L, device=dev)[None, :] < torch.tensor(kv_lens, device=dev)[:, None]).contiguous()
+
     def step():
-        pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal)
+        pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal, kpad_mask=kpad)
 
     def barrier():
         if dist is not None:
@@ -152,7 +160,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t_wall, t_dev = float(t[0]), float(t[1])
 
-    f_fwd = attention_flops(E, L, L, QH, B, causal=causal)
+    f_fwd = attention_flops(E, L, L, QH, B, causal=causal, kv_lens=kv_lens)
     by_fwd = attention_bytes(E, L, L, QH, KH, B, q.element_size())
     ms_per_step = t_wall / args.steps * 1e3
     value = world * f_fwd / (t_wall / args.steps) / 1e12
@@ -164,8 +172,8 @@ def main():
     if not args.no_bwd:
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ws = torch.empty(pkg.bwd_workspace_bytes(q, k, v, causal=causal), dtype=torch.uint8, device=dev)
-        fb = lambda: (pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal),
-                      pkg.fa_bwd_into(dq, dk, dv, None, ws, do, o, ms, ls, q, k, v, causal=causal))
+        fb = lambda: (pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal, kpad_mask=kpad),
+                      pkg.fa_bwd_into(dq, dk, dv, None, ws, do, o, ms, ls, q, k, v, causal=causal, kpad_mask=kpad))
         nb = max(args.steps // 4, 5)
         for _ in range(max(args.warmup // 4, 2)):
             fb()
@@ -211,7 +219,8 @@ def main():
         except Exception:                               # noqa: BLE001
             traffic = None
     out = {
-        "metric": "attention TFLOPs/s + GB/s (fwd, fwd+bwd) at E=64,L=4096,H=4,B=4",
+        "metric": "attention TFLOPs/s + GB/s (fwd, fwd+bwd) at E=64,L=4096,H=4,B=4" if args.config == "c2" else
+                  f"attention TFLOPs/s + GB/s (fwd, fwd+bwd), workload {args.config}",
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtn, "data": "synthetic",

@@ -1,0 +1,114 @@
+# NNopHIPExt.jl -- package extension that routes NNop's Flash Attention to libnnop_hip.so on AMD GPUs.
+#
+# SOURCE ONLY: there is no Julia in the build image, so this file is not executed by the test-suite;
+# the identical C calls are exercised from Python (nnop.jl_amd/_lib.py + attention.py).  It has the
+# shape of the reference's own extension (ext/NNopAMDGPUExt.jl:1-11): it only ADDS METHODS to
+# functions owned by NNop, so nothing else in the package changes:
+#
+#   NNop._shared_memory(::ROCBackend, device_id)             ext/NNopAMDGPUExt.jl:6-9
+#   NNop._flash_attention(q,k,v,pair; causal,kpad_mask)       src/attention.jl:133-177   -> (o, ms, ls)
+#   NNop.∇flash_attention(Δ,o,ms,ls,q,k,v,pair; causal,...)   src/attention_bwd.jl:199-275 -> (dq,dk,dv,dpair)
+#
+# `flash_attention` and the ChainRules `rrule` (src/attention_crc.jl:4-31) call these generically, so
+# `NNop.flash_attention(q, k, v; causal)` and `Zygote.gradient` keep working unchanged.
+#
+# Install (see INTEGRATION.md):  in NNop's Project.toml
+#     [extensions]
+#     NNopHIPExt = "AMDGPU"          # replaces / sits beside NNopAMDGPUExt
+# and put this file at ext/NNopHIPExt.jl; point ENV["NNOP_HIP_LIB"] at libnnop_hip.so.
+module NNopHIPExt
+
+using AMDGPU
+using NNop
+
+const LIB = Ref{String}("")
+libnnop() = isempty(LIB[]) ? (LIB[] = get(ENV, "NNOP_HIP_LIB", "libnnop_hip.so")) : LIB[]
+
+# struct nnop_fa_desc (include/nnop_hip.h)
+struct FaDesc
+    dtype::Int32; emb::Int32; ql::Int32; kl::Int32; qh::Int32; kh::Int32; batch::Int32; causal::Int32
+    emb_k::Int32; emb_v::Int32; kl_v::Int32; kh_v::Int32
+end
+
+# nnop_dtype
+nnop_dtype(::Type{Float32}) = Int32(0)
+nnop_dtype(::Type{Float16}) = Int32(1)
+nnop_dtype(::Type{Core.BFloat16}) = Int32(2)          # Julia >= 1.11; BFloat16s.BFloat16 has the same bits
+const HipFloat = Union{Float32, Float16, Core.BFloat16}
+
+# nnop_status -> the reference's ErrorException messages (src/attention.jl:141-144, :204)
+function check(st::Cint, q, k, v)
+    st == 0 && return
+    QE, KE = size(q, 1), size(k, 1)
+    st == -1 && error("Embedding dim of Q `$QE` must be the same as of K `$KE`.")
+    st == -2 && error("Shapes of K `$(size(k))` and V `$(size(v))` must be the same.")
+    st == -3 && error("Only power-of-2 embedding dims are supported.")
+    st == -4 && error("Number of query heads `$(size(q, 3))` must be divisible by number of KV heads `$(size(k, 3))`.")
+    st == -7 && error("Failed to find groupsize for Flash Attention that satisfies Shared Memory constraint.")
+    msg = unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st))
+    error("libnnop_hip: $msg")
+end
+
+desc(q, k, v, causal) = FaDesc(nnop_dtype(eltype(q)), size(q, 1), size(q, 2), size(k, 2), size(q, 3), size(k, 3),
+                               size(q, 4), causal ? 1 : 0, size(k, 1), size(v, 1), size(v, 2), size(v, 3))
+
+devptr(x) = Ptr{Cvoid}(UInt(pointer(x)))             # device VA of a ROCArray
+devptr(::Nothing) = Ptr{Cvoid}(0)
+hipstream() = Ptr{Cvoid}(UInt(AMDGPU.stream().stream))   # the task-local HIP stream the arrays live on
+
+# ext/NNopAMDGPUExt.jl:6-9 (device_id is 1-based in AMDGPU.devices())
+function NNop._shared_memory(::ROCBackend, device_id::Integer)
+    out = Ref{UInt64}(0)
+    st = ccall((:nnop_shared_memory, libnnop()), Cint, (Cint, Ptr{UInt64}), device_id - 1, out)
+    st == 0 || error("nnop_shared_memory failed ($st)")
+    return out[]
+end
+
+# src/attention.jl:133-177
+function NNop._flash_attention(
+    q::ROCArray{T,4}, k::ROCArray{T,4}, v::ROCArray{T,4},
+    pair::Union{Nothing,ROCArray{T,4}} = nothing;
+    causal::Bool, kpad_mask::Union{Nothing,ROCMatrix{Bool}} = nothing,
+) where T <: HipFloat
+    d = Ref(desc(q, k, v, causal))
+    o  = similar(q)                                            # :166
+    ms = ROCArray{T}(undef, size(q, 2), size(q, 3), size(q, 4))  # :167  (QL, QH, B)
+    ls = similar(ms)                                           # :168
+    st = ccall((:nnop_fa_fwd, libnnop()), Cint,
+        (Ptr{FaDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        d, devptr(o), devptr(ms), devptr(ls), devptr(q), devptr(k), devptr(v), devptr(pair), devptr(kpad_mask), hipstream())
+    check(st, q, k, v)
+    return o, ms, ls                                           # asynchronous, like the KA launch (:170-176)
+end
+
+# src/attention_bwd.jl:199-275
+function NNop.∇flash_attention(
+    Δ::ROCArray{T,4},
+    o::ROCArray{T,4}, ms::ROCArray{T,3}, ls::ROCArray{T,3},
+    q::ROCArray{T,4}, k::ROCArray{T,4}, v::ROCArray{T,4},
+    pair::Union{Nothing,ROCArray{T,4}} = nothing;
+    causal::Bool, kpad_mask::Union{Nothing,ROCMatrix{Bool}} = nothing,
+) where T <: HipFloat
+    d = Ref(desc(q, k, v, causal))
+    nbytes = ccall((:nnop_fa_bwd_workspace_bytes, libnnop()), Csize_t, (Ptr{FaDesc},), d)
+    if nbytes == 0                                             # invalid descriptor: fetch the status
+        st = ccall((:nnop_fa_bwd, libnnop()), Cint,
+            (Ptr{FaDesc}, ntuple(_ -> Ptr{Cvoid}, 14)..., Csize_t, Ptr{Cvoid}),
+            d, ntuple(_ -> Ptr{Cvoid}(0), 14)..., 0, Ptr{Cvoid}(0))
+        check(st, q, k, v)
+    end
+    dq, dk, dv = similar(q), similar(k), similar(v)           # fully overwritten by the library
+    dp = isnothing(pair) ? nothing : similar(pair)
+    ws = ROCArray{UInt8}(undef, nbytes)                        # replaces Δ_scaled / δ (:224-225)
+    st = ccall((:nnop_fa_bwd, libnnop()), Cint,
+        (Ptr{FaDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},          # dq dk dv dpair
+         Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},                      # Δ o ms ls
+         Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},          # q k v pair kpad_mask
+         Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),                                    # workspace, bytes, stream
+        d, devptr(dq), devptr(dk), devptr(dv), devptr(dp), devptr(Δ), devptr(o), devptr(ms), devptr(ls),
+        devptr(q), devptr(k), devptr(v), devptr(pair), devptr(kpad_mask), devptr(ws), nbytes, hipstream())
+    check(st, q, k, v)
+    return dq, dk, dv, dp
+end
+
+end # module
