@@ -43,6 +43,19 @@
 #ifndef NNOP_ABL
 #define NNOP_ABL 0
 #endif
+// Variant switches for A/B timing (make VAR="-DNNOP_V_...=0"); defaults are the shipped configuration.
+#ifndef NNOP_V_PREFETCH
+#define NNOP_V_PREFETCH 1
+#endif
+#ifndef NNOP_V_DEEP
+#define NNOP_V_DEEP 1
+#endif
+#ifndef NNOP_V_MFMASUM
+#define NNOP_V_MFMASUM 1
+#endif
+#ifndef NNOP_V_SETPRIO
+#define NNOP_V_SETPRIO 0
+#endif
 
 namespace nnop {
 
@@ -60,6 +73,7 @@ struct FwdParams {
     int   n_qblk;            // ceil(QL / (32*QB*NW))
     int   n_wg;              // n_qblk * QH * B
     float scale;             // 1/sqrt(E)
+    int   stagger;           // experiment: s_sleep units for the odd co-resident workgroup (0 = off)
 };
 
 // MODE 0: plain   -- KL % BK == 0, no causal, no kpad, no pair: every logit is live
@@ -90,11 +104,11 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
     // kMfmaSum : row sums on the matrix pipe
     constexpr bool k16 = sizeof(T) == 2;
     constexpr bool kPipe = k16 && (E <= 64 || MODE == 0);
-    constexpr bool kPrefetch = k16 && (QB == 2 ? E <= 64 : (MODE == 0 && E <= 64));
+    constexpr bool kPrefetch = NNOP_V_PREFETCH && k16 && (QB == 2 ? E <= 64 : (MODE == 0 && E <= 64));
     constexpr int  PFK = kPrefetch ? (NKF <= 8 ? NKF : 8) : 0;
     constexpr int  PFV = kPrefetch ? (NVF <= 8 ? NVF : 8) : 0;
-    constexpr bool kDeep = kPipe && E <= 64 && (QB == 2 || (MODE == 0 && NW == 8));
-    constexpr bool kMfmaSum = k16 && E <= 64 && (QB == 2 || MODE == 0);
+    constexpr bool kDeep = NNOP_V_DEEP && kPipe && E <= 64 && (QB == 2 || (MODE == 0 && NW == 8));
+    constexpr bool kMfmaSum = NNOP_V_MFMASUM && k16 && E <= 64 && (QB == 2 || MODE == 0);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -102,6 +116,14 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+
+    // experiment (NNOP_FWD_STAGGER): de-phase co-resident workgroups.  HW_ID.TG_ID (bits 19:16) numbers the
+    // workgroups resident on this CU; the odd one starts late so that its LDS / barrier phases fall into
+    // the other's MFMA phase.  Timing only, never correctness.
+    if (p.stagger > 0) {
+        const unsigned tg = __builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11));
+        if (tg & 1) for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(8);
+    }
 
     // ---- which (batch, q-head, q-block) -------------------------------------------------
     int lin = xcd_remap((int)blockIdx.x, p.n_wg);
@@ -235,6 +257,9 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
     };
     // ---- X(t): S'^T = K Q^T - m2 for kv tile t, all query blocks (MFMA) ----------------------
     auto qk_tile = [&](const char* kimg, const frag_t (&kf)[PFK > 0 ? PFK : 1], f32x16 (&s)[QB][KB]) {
+#if NNOP_V_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
@@ -254,6 +279,9 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
                 }
             }
         }
+#if NNOP_V_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     // wave-uniform: which keys of tile t are valid (bounds + key padding); does it need masking
     auto tile_valid = [&](int t) -> uint64_t {

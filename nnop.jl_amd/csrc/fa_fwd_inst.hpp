@@ -7,6 +7,7 @@
 // workgroup is chosen, from how many workgroups the problem yields against the chip's 256 CUs.
 #pragma once
 #include "fa_fwd.hpp"
+#include "fa_fwd_split.hpp"
 #include "fa_launch.hpp"
 #include <math.h>
 
@@ -37,8 +38,36 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.n_wg = (int)n_wg;
     p.scale = (float)(1.0 / sqrt((double)E));        // T(inv(sqrt(QE))), src/attention.jl:154
+    p.stagger = env_int("NNOP_FWD_STAGGER", 0);
     const int lds_pad = env_int("NNOP_FWD_LDS_PAD", 0);   // debugging aid: limits workgroups per CU
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds + lds_pad, s, p);
+    return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
+}
+
+// split-KV form (fa_fwd_split.hpp): 16 waves per workgroup, plain mode, 16-bit types, E <= 64
+template <typename T, int E>
+static int launch_fwd_split(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+    constexpr int lds = fa_fwd_split_lds_bytes<T, E>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fa_fwd_split_kernel<T, E>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return NNOP_ERR_HIP;
+        }
+    }
+    FwdParams p;
+    p.o = a.o; p.ms = a.ms; p.ls = a.ls;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.pair = nullptr; p.kpad = nullptr;
+    p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
+    p.causal = 0;
+    p.n_qblk = (d.ql + 255) / 256;
+    const long long n_wg = (long long)p.n_qblk * d.qh * d.batch;
+    if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    p.n_wg = (int)n_wg;
+    p.scale = (float)(1.0 / sqrt((double)E));
+    p.stagger = 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), lds, s, p);
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
@@ -56,6 +85,11 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     // Workgroup shape: 8 waves x 32 rows (256-row workgroups) when that still yields >= one
     // workgroup per CU, else 4 waves x 32 rows so that small problems spread over more CUs.
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
+    if constexpr (sizeof(T) == 2 && E <= 64) {
+        // default for plain mode: 16-wave split-KV workgroups (4 waves per SIMD); measured 5-13 % faster than
+        // the 8-wave form from 64 to 4096 workgroups.  NNOP_FWD_SPLIT=0 disables.
+        if (mode == 0 && d.ql > 128 && d.kl >= 128 && env_int("NNOP_FWD_SPLIT", 1)) return launch_fwd_split<T, E>(d, a, s);
+    }
     int nw = 8, qb = 1;
     if (wg256 < 256 || d.ql <= 128) nw = 4;
     if (E >= 128 && mode != 0) nw = 4;               // the masked E=128 body: 4 waves per workgroup

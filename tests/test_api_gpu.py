@@ -123,6 +123,7 @@ def test_bitwise_reproducible_across_launches_and_workgroup_shapes(pkg, dev, dt,
     d = make_inputs(31, 2, 4, 2, 517, 517, E, dt, dev, pad=pad)
     flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
     outs = []
+    monkeypatch.setenv("NNOP_FWD_SPLIT", "0")      # compare the 8-wave and 4-wave forms of the same per-row arithmetic
     for nw in ("8", "4", "4", "8"):
         monkeypatch.setenv("NNOP_FWD_NW", nw)
         flush.fill_(1)
@@ -133,3 +134,29 @@ def test_bitwise_reproducible_across_launches_and_workgroup_shapes(pkg, dev, dt,
     for other in outs[1:]:
         for a, b, name in zip(outs[0], other, ("o", "ms", "ls", "dq", "dk", "dv")):
             assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), name
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("E,QL,KL", [(64, 1024, 1024), (64, 300, 192), (32, 512, 576), (16, 257, 128), (64, 4096, 4096)])
+def test_split_kv_form_matches_plain_form_and_is_reproducible(pkg, dev, dt, E, QL, KL, monkeypatch):
+    """The 16-wave split-KV forward (default in plain mode) sums the keys in a different order than the 8-wave
+    form, so the two agree to rounding, not bitwise; each is bitwise reproducible; both match the oracle."""
+    d = make_inputs(33, 2, 2, 2, QL, KL, E, dt, dev, need_do=False)
+    monkeypatch.setenv("NNOP_FWD_SPLIT", "1")
+    a = pkg._flash_attention(d["q"], d["k"], d["v"], causal=False)
+    b = pkg._flash_attention(d["q"], d["k"], d["v"], causal=False)
+    monkeypatch.setenv("NNOP_FWD_SPLIT", "0")
+    c = pkg._flash_attention(d["q"], d["k"], d["v"], causal=False)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    if QL * KL <= 1024 * 1024:
+        o_ref, ms_ref, ls_ref = oracle_fwd(d, False)
+        for res in (a, c):
+            assert_close("o", res[0], o_ref, dt)
+            assert_close("ms", res[1], ms_ref, dt)
+            lse = res[1].double().cpu().numpy() + np.log(res[2].double().cpu().numpy())
+            assert_close("lse", lse, ms_ref + np.log(ls_ref), dt)
+    else:
+        rel = float((a[0].float() - c[0].float()).abs().max() / c[0].float().abs().max())
+        assert rel < 1e-2
