@@ -124,12 +124,12 @@ template <typename T, int E> struct BwdImgs {
 // -------------------------------------------------------------------------------------------------
 template <typename T, int E, int NW, int BQ>
 constexpr int fa_bwd_dkdv_lds_bytes() {
-    constexpr bool kv_regs = sizeof(T) == 2 || E <= 64;
+    constexpr bool kv_regs = E <= 64;
     return (kv_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) + 2 * (2 * BwdImgs<T, E>::both(BQ) + 2 * BQ * 4);
 }
 
 template <typename T, int E, int NW, int BQ, bool kGeneral>
-__global__ __launch_bounds__(NW * 64) void fa_bwd_dkdv_kernel(const BwdParams p) {
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void fa_bwd_dkdv_kernel(const BwdParams p) {
     using frag_t = typename Elem<T>::frag;
     using Imgs = BwdImgs<T, E>;
     using Row = typename Imgs::Row;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NW * 64) void fa_bwd_dkdv_kernel(const BwdParams p)
     constexpr int KS = E / 16;
     constexpr int EB = (E + 31) / 32;
     constexpr int QB = BQ / 32;
-    constexpr bool kKVRegs = sizeof(T) == 2 || E <= 64;
+    constexpr bool kKVRegs = E <= 64;     // E = 128: dK^T, dV^T accumulators already take 128 registers
     constexpr int KVIMG = kKVRegs ? 0 : Row::bytes(32 * NW);
     constexpr int QIMG = Imgs::both(BQ);
     constexpr int BUF = 2 * QIMG + 2 * BQ * 4;
@@ -345,13 +345,13 @@ __global__ __launch_bounds__(NW * 64) void fa_bwd_dkdv_kernel(const BwdParams p)
 // -------------------------------------------------------------------------------------------------
 template <typename T, int E, int NW, int BK>
 constexpr int fa_bwd_dq_lds_bytes() {
-    constexpr bool qdo_regs = sizeof(T) == 2 || E <= 64;
+    constexpr bool qdo_regs = E <= (sizeof(T) == 2 ? 64 : 32);
     return (qdo_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) +
            2 * (BwdImgs<T, E>::both(BK) + RowImg<T, E>::bytes(BK));
 }
 
 template <typename T, int E, int NW, int BK, bool kGeneral>
-__global__ __launch_bounds__(NW * 64) void fa_bwd_dq_kernel(const BwdParams p) {
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void fa_bwd_dq_kernel(const BwdParams p) {
     using frag_t = typename Elem<T>::frag;
     using Imgs = BwdImgs<T, E>;
     using Row = typename Imgs::Row;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NW * 64) void fa_bwd_dq_kernel(const BwdParams p) {
     constexpr int KS = E / 16;
     constexpr int EB = (E + 31) / 32;
     constexpr int KB = BK / 32;
-    constexpr bool kQRegs = sizeof(T) == 2 || E <= 64;
+    constexpr bool kQRegs = E <= (sizeof(T) == 2 ? 64 : 32);   // else Q, dO fragments come from LDS row images
     constexpr int QIMG = kQRegs ? 0 : Row::bytes(32 * NW);
     constexpr int KIMG = Imgs::both(BK);
     constexpr int BUF = KIMG + Row::bytes(BK);

@@ -15,7 +15,7 @@ template <typename T, int E> struct BwdCfg {
     static constexpr int NW_KV = (kF32 && E > 64) ? 2 : 4;
     static constexpr int BQ    = (kF32 || E > 64) ? 32 : 64;
     static constexpr int NW_Q  = (kF32 && E > 64) ? 2 : 4;
-    static constexpr int BK    = (kF32 && E > 64) ? 32 : 64;
+    static constexpr int BK    = (E > 64) ? 32 : 64;
 };
 
 template <typename K> static int set_lds(K kern, int lds) {
