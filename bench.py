@@ -13,7 +13,7 @@ on the H x B axis -- (batch, head) slices are independent, SURVEY.md section 8(e
 collective; the optional all-gather of O is timed separately.
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (fa_fwd_kernel): algorithmic FLOPs per launch / average launch
+  roofline     -- dominant kernel (fa_fwd_split_kernel at C2): algorithmic FLOPs per launch / average launch
                   duration measured here with HIP events on the launch stream, against the dense
                   bf16 MFMA peak (2516.6 TFLOP/s = 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz).
   cpu_baseline -- the oracle's fp32 port of the reference's naive attention
@@ -112,13 +112,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NNOP_BENCH_REHEARSE=1: N ranks on ONE GPU with gloo, to rehearse the multi-rank control flow on a 1-GPU box
+    # (numbers are meaningless then); the real run is one rank per GPU over RCCL.
+    rehearse = os.environ.get("NNOP_BENCH_REHEARSE") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+    red_dev = torch.device("cpu") if rehearse else dev        # where the timing all-reduce lives
 
     dtn, E, L, QH, KH, B, causal = CONFIGS[args.config]
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtn]
@@ -155,7 +163,7 @@ def main():
     t_wall = time.perf_counter() - t0
     barrier()
     t_dev = ev0.elapsed_time(ev1) * 1e-3                 # HIP events on the launch stream
-    t = torch.tensor([t_wall, t_dev], device=dev, dtype=torch.float64)
+    t = torch.tensor([t_wall, t_dev], device=red_dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t_wall, t_dev = float(t[0]), float(t[1])
@@ -183,7 +191,7 @@ def main():
             fb()
         ev1.record()
         torch.cuda.synchronize()
-        tb = torch.tensor([ev0.elapsed_time(ev1) * 1e-3 / nb], device=dev, dtype=torch.float64)
+        tb = torch.tensor([ev0.elapsed_time(ev1) * 1e-3 / nb], device=red_dev, dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         t_fb = float(tb[0])
@@ -194,7 +202,7 @@ def main():
             "bwd_tflops": round(world * f_fwd * 2.5 / max(t_fb - kern_s, 1e-9) / 1e12, 2),
             "fwd_bwd_gbps": round(world * by_fb / t_fb / 1e9, 1),
         })
-    if args.gather and dist is not None:
+    if args.gather and dist is not None and not rehearse:
         full = torch.empty((world,) + tuple(o.shape), dtype=o.dtype, device=dev)
         for _ in range(2):
             dist.all_gather_into_tensor(full, o)
@@ -231,7 +239,8 @@ def main():
         "fwd_gbps": round(world * by_fwd / (t_wall / args.steps) / 1e9, 1),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtn], "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_TFLOPS[dtn], 4), "traffic": traffic,
-                     "kernel": "fa_fwd_kernel", "avg_launch_us": round(kern_s * 1e6, 2),
+                     "kernel": ("fa_fwd_split_kernel" if (dtn != "f32" and E <= 64 and not causal and kpad is None)
+                                else "fa_fwd_kernel"), "avg_launch_us": round(kern_s * 1e6, 2),
                      "flops_per_launch": f_fwd, "algorithmic_bytes_per_launch": by_fwd,
                      "hbm_frac_at_this_rate": round(by_fwd / kern_s / 1e9 / HBM_PEAK_GBS, 4)},
     }
