@@ -122,10 +122,17 @@ template <typename T, int E> struct BwdImgs {
 //   dV^T += dO^T P        : A = dO columns (LDS transposed read), B = P  straight from accumulators
 //   dK^T += Q^T dS        : A = Q columns,                        B = dS straight from accumulators
 // -------------------------------------------------------------------------------------------------
+// kSingle (E = 128, 16-bit): the streamed q-tile is single-buffered in LDS -- the next tile is prefetched into
+// registers during the compute phase and written after a barrier -- which frees the LDS for 7-wave workgroups
+// (224 keys: 112 KiB of K, V images + 32 KiB of tile), i.e. ~2 waves per SIMD instead of 1.
+// (chosen by the launcher: NW == 7 <=> single-buffered)
+template <typename T, int E, int NW> constexpr bool fa_bwd_single() { return sizeof(T) == 2 && E > 64 && NW == 7; }
+
 template <typename T, int E, int NW, int BQ>
 constexpr int fa_bwd_dkdv_lds_bytes() {
     constexpr bool kv_regs = E <= 64;
-    return (kv_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) + 2 * (2 * BwdImgs<T, E>::both(BQ) + 2 * BQ * 4);
+    constexpr int nbuf = fa_bwd_single<T, E, NW>() ? 1 : 2;
+    return (kv_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) + nbuf * (2 * BwdImgs<T, E>::both(BQ) + 2 * BQ * 4);
 }
 
 template <typename T, int E, int NW, int BQ, bool kGeneral>
@@ -141,7 +148,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     constexpr bool kKVRegs = E <= 64;     // E = 128: dK^T, dV^T accumulators already take 128 registers
     constexpr int KVIMG = kKVRegs ? 0 : Row::bytes(32 * NW);
     constexpr int QIMG = Imgs::both(BQ);
-    constexpr int BUF = 2 * QIMG + 2 * BQ * 4;
+    constexpr bool kSingle = fa_bwd_single<T, E, NW>();
+    constexpr int BUF = kSingle ? 0 : 2 * QIMG + 2 * BQ * 4;      // distance between the two buffers (0: one buffer)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -325,6 +333,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             }
         }
 
+        if constexpr (kSingle) __syncthreads();          // every wave is done reading the (only) buffer
         if (more) stage_write(nxt);
         __syncthreads();
     }
@@ -346,8 +355,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
 template <typename T, int E, int NW, int BK>
 constexpr int fa_bwd_dq_lds_bytes() {
     constexpr bool qdo_regs = E <= (sizeof(T) == 2 ? 64 : 32);
+    constexpr int nbuf = fa_bwd_single<T, E, NW>() ? 1 : 2;
     return (qdo_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) +
-           2 * (BwdImgs<T, E>::both(BK) + RowImg<T, E>::bytes(BK));
+           nbuf * (BwdImgs<T, E>::both(BK) + RowImg<T, E>::bytes(BK));
 }
 
 template <typename T, int E, int NW, int BK, bool kGeneral>
@@ -363,7 +373,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     constexpr bool kQRegs = E <= (sizeof(T) == 2 ? 64 : 32);   // else Q, dO fragments come from LDS row images
     constexpr int QIMG = kQRegs ? 0 : Row::bytes(32 * NW);
     constexpr int KIMG = Imgs::both(BK);
-    constexpr int BUF = KIMG + Row::bytes(BK);
+    constexpr bool kSingle = fa_bwd_single<T, E, NW>();
+    constexpr int BUF = kSingle ? 0 : KIMG + Row::bytes(BK);      // distance between the two buffers (0: one buffer)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -531,6 +542,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             }
         }
 
+        if constexpr (kSingle) __syncthreads();          // every wave is done reading the (only) buffer
         if (more) stage_write(nxt);
         __syncthreads();
     }

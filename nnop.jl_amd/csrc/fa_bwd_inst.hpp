@@ -15,6 +15,9 @@ template <typename T, int E> struct BwdCfg {
     static constexpr int NW_KV = (kF32 && E > 64) ? 2 : 4;
     static constexpr int BQ    = (kF32 || E > 64) ? 32 : 64;
     static constexpr int NW_Q  = (kF32 && E > 64) ? 2 : 4;
+    // 16-bit E = 128, large grids: 7 waves (224 keys / queries per workgroup) with single-buffered tiles ->
+    // ~2 waves per SIMD instead of 1 (LDS-limited); small grids keep 4 waves (finer quantization over 256 CUs)
+    static constexpr bool kBig7 = !kF32 && E > 64;
     static constexpr int BK    = (E > 64) ? 32 : 64;
 };
 
@@ -25,6 +28,36 @@ template <typename K> static int set_lds(K kern, int lds) {
             return NNOP_ERR_HIP;
         }
     }
+    return NNOP_OK;
+}
+
+template <typename T, int E, int NW, int BQ, bool kGeneral>
+static int launch_dkdv(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
+    constexpr int lds = fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fa_bwd_dkdv_kernel<T, E, NW, BQ, kGeneral>;
+    if (set_lds(kern, lds) != NNOP_OK) return NNOP_ERR_HIP;
+    BwdParams pk = p;
+    pk.n_blk = (d.kl + 32 * NW - 1) / (32 * NW);
+    const long long n_wg = (long long)pk.n_blk * d.kh * d.batch;
+    if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    pk.n_wg = (int)n_wg;
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, s, pk);
+    return NNOP_OK;
+}
+
+template <typename T, int E, int NW, int BK, bool kGeneral>
+static int launch_dq(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
+    constexpr int lds = fa_bwd_dq_lds_bytes<T, E, NW, BK>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fa_bwd_dq_kernel<T, E, NW, BK, kGeneral>;
+    if (set_lds(kern, lds) != NNOP_OK) return NNOP_ERR_HIP;
+    BwdParams pq = p;
+    pq.n_blk = (d.ql + 32 * NW - 1) / (32 * NW);
+    const long long n_wg = (long long)pq.n_blk * d.qh * d.batch;
+    if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    pq.n_wg = (int)n_wg;
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, s, pq);
     return NNOP_OK;
 }
 
@@ -55,33 +88,28 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         const size_t bytes = (size_t)d.batch * d.kl * d.ql * d.qh * sizeof(T);
         if (hipMemsetAsync(p.dpair, 0, bytes, s) != hipSuccess) { (void)hipGetLastError(); return NNOP_ERR_HIP; }
     }
+    const int big_thr = env_int("NNOP_BWD_BIG7", 512);     // workgroups (7-wave form) from which it is used
     // 3. dK, dV
     {
-        constexpr int NW = C::NW_KV, BQ = C::BQ;
-        constexpr int lds = fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>();
-        static_assert(lds <= 160 * 1024, "LDS budget");
-        auto kern = fa_bwd_dkdv_kernel<T, E, NW, BQ, kGeneral>;
-        if (set_lds(kern, lds) != NNOP_OK) return NNOP_ERR_HIP;
-        BwdParams pk = p;
-        pk.n_blk = (d.kl + 32 * NW - 1) / (32 * NW);
-        const long long n_wg = (long long)pk.n_blk * d.kh * d.batch;
-        if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
-        pk.n_wg = (int)n_wg;
-        hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, s, pk);
+        int st = NNOP_OK;
+        bool done = false;
+        if constexpr (C::kBig7) {
+            const long long n7 = (long long)((d.kl + 223) / 224) * d.kh * d.batch;
+            if (n7 >= big_thr) { st = launch_dkdv<T, E, 7, C::BQ, kGeneral>(d, p, s); done = true; }
+        }
+        if (!done) st = launch_dkdv<T, E, C::NW_KV, C::BQ, kGeneral>(d, p, s);
+        if (st != NNOP_OK) return st;
     }
     // 4. dQ
     {
-        constexpr int NW = C::NW_Q, BK = C::BK;
-        constexpr int lds = fa_bwd_dq_lds_bytes<T, E, NW, BK>();
-        static_assert(lds <= 160 * 1024, "LDS budget");
-        auto kern = fa_bwd_dq_kernel<T, E, NW, BK, kGeneral>;
-        if (set_lds(kern, lds) != NNOP_OK) return NNOP_ERR_HIP;
-        BwdParams pq = p;
-        pq.n_blk = (d.ql + 32 * NW - 1) / (32 * NW);
-        const long long n_wg = (long long)pq.n_blk * d.qh * d.batch;
-        if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
-        pq.n_wg = (int)n_wg;
-        hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, s, pq);
+        int st = NNOP_OK;
+        bool done = false;
+        if constexpr (C::kBig7) {
+            const long long n7 = (long long)((d.ql + 223) / 224) * d.qh * d.batch;
+            if (n7 >= big_thr) { st = launch_dq<T, E, 7, C::BK, kGeneral>(d, p, s); done = true; }
+        }
+        if (!done) st = launch_dq<T, E, C::NW_Q, C::BK, kGeneral>(d, p, s);
+        if (st != NNOP_OK) return st;
     }
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }

@@ -15,9 +15,9 @@ namespace nnop {
 
 template <typename T, int E, int NW, int MODE, int QB>
 static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
-    // 64-key tiles, except where the masked body would not fit 256 VGPRs (E = 128, QB = 1) and fp32
-    // E = 128 (LDS: 2 x (K + V) x 64 keys x 512 B = 128 KiB would leave one workgroup per CU)
-    constexpr int BK = (E >= 128 && ((MODE != 0 && QB == 1) || sizeof(T) == 4)) ? 32 : 64;
+    // 64-key tiles, except the E = 128 pair-bias body (register budget) and fp32 E = 128
+    // (LDS: 2 x (K + V) x 64 keys x 512 B = 128 KiB would leave one workgroup per CU)
+    constexpr int BK = (E >= 128 && (MODE == 2 || sizeof(T) == 4)) ? 32 : 64;
     constexpr int lds = fa_fwd_lds_bytes<T, E, BK>();
     static_assert(lds <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
     auto kern = fa_fwd_kernel<T, E, NW, BK, MODE, QB>;
@@ -92,7 +92,7 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     }
     int nw = 8, qb = 1;
     if (wg256 < 256 || d.ql <= 128) nw = 4;
-    if (E >= 128 && mode != 0) nw = 4;               // the masked E=128 body: 4 waves per workgroup
+    if (E >= 128 && mode == 2) nw = 4;               // the E=128 pair-bias body: 4 waves per workgroup
     nw = env_int("NNOP_FWD_NW", nw);
     // QB = 2 (4 waves x 64 rows, one wave per SIMD) is EXPERIMENTAL and opt-in: it halves the LDS
     // fragment traffic per MFMA, but hipcc's allocator then shuttles the score tiles between AGPRs

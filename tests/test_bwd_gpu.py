@@ -87,3 +87,14 @@ def test_rrule_through_autograd(pkg, dev, dt):
     with torch.no_grad():      # not under AD: plain forward, returns o only (attention_crc.jl:11-13)
         o2 = pkg.flash_attention(d["q"], d["k"], d["v"], d["pair"], causal=True, kpad_mask=d["mask"])
     assert torch.equal(o2, o.detach())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_e128_seven_wave_backward_form(pkg, dev, dt, causal, monkeypatch):
+    """E = 128 backward has two workgroup shapes (4 waves / 7 waves with single-buffered tiles, chosen by grid
+    size).  Force each and check both against the oracle; 224-row blocks exercise ragged block tails."""
+    d = make_inputs(17, 2, 4, 2, 700, 700, 128, dt, dev, pad="ref" if causal else None)
+    for thr in ("1", "100000000"):
+        monkeypatch.setenv("NNOP_BWD_BIG7", thr)
+        check_bwd(pkg, d, causal, dt)
