@@ -135,8 +135,11 @@ constexpr int fa_bwd_dkdv_lds_bytes() {
     return (kv_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) + nbuf * (2 * BwdImgs<T, E>::both(BQ) + 2 * BQ * 4);
 }
 
-template <typename T, int E, int NW, int BQ, bool kGeneral>
+// MODE 0 plain / 1 masked (causal, key padding) / 2 masked + pair bias and dpair  (as in fa_fwd.hpp)
+template <typename T, int E, int NW, int BQ, int MODE>
 __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void fa_bwd_dkdv_kernel(const BwdParams p) {
+    constexpr bool kGeneral = MODE != 0;
+    constexpr bool kPair = MODE == 2;
     using frag_t = typename Elem<T>::frag;
     using Imgs = BwdImgs<T, E>;
     using Row = typename Imgs::Row;
@@ -294,17 +297,19 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                 if constexpr (kGeneral) {
                     ok = kvalid;
                     if (diag) ok = ok && (qrow_i >= key);
-                    if (p.pair && ok && qrow_i < p.QL) {
-                        const size_t po = (((size_t)b * p.KL + key) * p.QL + qrow_i) * p.QH + qh;
-                        x += to_f32(((const T*)p.pair)[po]) * kLog2e;
+                    if constexpr (kPair) {
+                        if (ok && qrow_i < p.QL) {
+                            const size_t po = (((size_t)b * p.KL + key) * p.QL + qrow_i) * p.QH + qh;
+                            x += to_f32(((const T*)p.pair)[po]) * kLog2e;
+                        }
                     }
                 }
                 float pr = fast_exp2(x);
                 if constexpr (kGeneral) pr = ok ? pr : 0.f;
                 s[i] = pr;
                 ds[i] = pr * dp[i];
-                if constexpr (kGeneral) {
-                    if (p.dpair && key < p.KL && qrow_i < p.QL) {
+                if constexpr (kPair) {
+                    if (key < p.KL && qrow_i < p.QL) {
                         const size_t po = (((size_t)b * p.KL + key) * p.QL + qrow_i) * p.QH + qh;
                         ((T*)p.dpair)[po] = from_f32<T>(ds[i]);
                     }
@@ -360,8 +365,10 @@ constexpr int fa_bwd_dq_lds_bytes() {
            nbuf * (BwdImgs<T, E>::both(BK) + RowImg<T, E>::bytes(BK));
 }
 
-template <typename T, int E, int NW, int BK, bool kGeneral>
+template <typename T, int E, int NW, int BK, int MODE>
 __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void fa_bwd_dq_kernel(const BwdParams p) {
+    constexpr bool kGeneral = MODE != 0;
+    constexpr bool kPair = MODE == 2;
     using frag_t = typename Elem<T>::frag;
     using Imgs = BwdImgs<T, E>;
     using Row = typename Imgs::Row;
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             }
             if (valid == 0ull) skip = true;
             need_mask = (valid != ((BK < 64) ? ((1ull << BK) - 1ull) : ~0ull)) ||
-                        (p.causal && k0 + BK - 1 > q0w) || (p.pair != nullptr);
+                        (p.causal && k0 + BK - 1 > q0w) || kPair;
         }
 
         if (!skip) {
@@ -514,10 +521,12 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                             const int lr = (i & 3) + 8 * (i >> 2);
                             ok = (w >> lr) & 1u;
                             if (p.causal) ok = ok && (lr <= lim);
-                            if (p.pair && ok && qi < p.QL) {
-                                const int kkey = k0 + 32 * kb + lr + 4 * h;
-                                const size_t po = (((size_t)b * p.KL + kkey) * p.QL + qi) * p.QH + qh;
-                                x += to_f32(((const T*)p.pair)[po]) * kLog2e;
+                            if constexpr (kPair) {
+                                if (ok && qi < p.QL) {
+                                    const int kkey = k0 + 32 * kb + lr + 4 * h;
+                                    const size_t po = (((size_t)b * p.KL + kkey) * p.QL + qi) * p.QH + qh;
+                                    x += to_f32(((const T*)p.pair)[po]) * kLog2e;
+                                }
                             }
                         }
                     }

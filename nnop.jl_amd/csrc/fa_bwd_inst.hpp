@@ -31,11 +31,11 @@ template <typename K> static int set_lds(K kern, int lds) {
     return NNOP_OK;
 }
 
-template <typename T, int E, int NW, int BQ, bool kGeneral>
+template <typename T, int E, int NW, int BQ, int MODE>
 static int launch_dkdv(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
     constexpr int lds = fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = fa_bwd_dkdv_kernel<T, E, NW, BQ, kGeneral>;
+    auto kern = fa_bwd_dkdv_kernel<T, E, NW, BQ, MODE>;
     if (set_lds(kern, lds) != NNOP_OK) return NNOP_ERR_HIP;
     BwdParams pk = p;
     pk.n_blk = (d.kl + 32 * NW - 1) / (32 * NW);
@@ -46,11 +46,11 @@ static int launch_dkdv(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s)
     return NNOP_OK;
 }
 
-template <typename T, int E, int NW, int BK, bool kGeneral>
+template <typename T, int E, int NW, int BK, int MODE>
 static int launch_dq(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
     constexpr int lds = fa_bwd_dq_lds_bytes<T, E, NW, BK>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = fa_bwd_dq_kernel<T, E, NW, BK, kGeneral>;
+    auto kern = fa_bwd_dq_kernel<T, E, NW, BK, MODE>;
     if (set_lds(kern, lds) != NNOP_OK) return NNOP_ERR_HIP;
     BwdParams pq = p;
     pq.n_blk = (d.ql + 32 * NW - 1) / (32 * NW);
@@ -61,7 +61,7 @@ static int launch_dq(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
     return NNOP_OK;
 }
 
-template <typename T, int E, bool kGeneral>
+template <typename T, int E, int MODE>
 static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
     using C = BwdCfg<T, E>;
     BwdParams p;
@@ -95,9 +95,9 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         bool done = false;
         if constexpr (C::kBig7) {
             const long long n7 = (long long)((d.kl + 223) / 224) * d.kh * d.batch;
-            if (n7 >= big_thr) { st = launch_dkdv<T, E, 7, C::BQ, kGeneral>(d, p, s); done = true; }
+            if (n7 >= big_thr) { st = launch_dkdv<T, E, 7, C::BQ, MODE>(d, p, s); done = true; }
         }
-        if (!done) st = launch_dkdv<T, E, C::NW_KV, C::BQ, kGeneral>(d, p, s);
+        if (!done) st = launch_dkdv<T, E, C::NW_KV, C::BQ, MODE>(d, p, s);
         if (st != NNOP_OK) return st;
     }
     // 4. dQ
@@ -106,9 +106,9 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         bool done = false;
         if constexpr (C::kBig7) {
             const long long n7 = (long long)((d.ql + 223) / 224) * d.qh * d.batch;
-            if (n7 >= big_thr) { st = launch_dq<T, E, 7, C::BK, kGeneral>(d, p, s); done = true; }
+            if (n7 >= big_thr) { st = launch_dq<T, E, 7, C::BK, MODE>(d, p, s); done = true; }
         }
-        if (!done) st = launch_dq<T, E, C::NW_Q, C::BK, kGeneral>(d, p, s);
+        if (!done) st = launch_dq<T, E, C::NW_Q, C::BK, MODE>(d, p, s);
         if (st != NNOP_OK) return st;
     }
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
@@ -116,8 +116,9 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
 
 template <typename T, int E>
 static int launch_bwd_e(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
-    const bool general = d.causal || a.kpad || a.pair;
-    return general ? launch_bwd_cfg<T, E, true>(d, a, s) : launch_bwd_cfg<T, E, false>(d, a, s);
+    if (a.pair) return launch_bwd_cfg<T, E, 2>(d, a, s);
+    if (d.causal || a.kpad) return launch_bwd_cfg<T, E, 1>(d, a, s);
+    return launch_bwd_cfg<T, E, 0>(d, a, s);
 }
 
 template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
