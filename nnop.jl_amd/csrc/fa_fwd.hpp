@@ -22,9 +22,9 @@
 //   other                                         one straight-line block holds the QK^T MFMAs of
 //                                                 tile t+1, the exp/convert of tile t, the PV
 //                                                 MFMAs of tile t and the row max of tile t+1
-//   scale, max-subtraction, exp, row sum on the   Q pre-scaled by scale*log2e; -max is the MFMA's
-//   VALU per element                              initial accumulator, so P = exp2(S'); row sums
-//                                                 by MFMA (all-ones A operand)
+//   scale, max-subtraction, exp in T              one fp32 fma + v_exp per logit: P = exp2(s*c - m);
+//                                                 rescale deferred (threshold 2^8); row sums by MFMA
+//                                                 (all-ones A operand) where registers allow
 //
 // Work decomposition: workgroup = NW waves x QB x 32 consecutive query rows of one (batch, q-head);
 // kv tiles of BK keys.  QB = 2 (64 rows per wave, one wave per SIMD, 512-register budget) halves the
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
         if (t_w < n_live) n_live = t_w;
     }
 
-    // ---- Q fragments: B operand of S^T = K Q^T, straight from HBM into registers, PRE-SCALED by
-    // c2 = scale * log2(e) (one rounding to T per element, once per kernel): the MFMA then produces
-    // logits in log2 units and P = exp2(S') needs no per-element multiply.
+    // ---- Q fragments: B operand of S^T = K Q^T, straight from HBM into registers (raw: the scale is applied
+    // in fp32 inside the exp argument -- pre-scaling Q in T was measured: no faster, and 10-50x less accurate
+    // on large logits).
     const float c2 = p.scale * kLog2e;
     frag_t qf[QB][KS];
 #pragma unroll
@@ -186,11 +186,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
         const int qc = qi[z] < p.QL ? qi[z] : p.QL - 1;    // clamped for loads
         const T* qrow = qp + (size_t)qc * E;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const frag_t raw = *reinterpret_cast<const frag_t*>(qrow + 16 * ks + 8 * h);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[z][ks][j] = from_f32<T>(to_f32(raw[j]) * c2);
-        }
+        for (int ks = 0; ks < KS; ++ks) qf[z][ks] = *reinterpret_cast<const frag_t*>(qrow + 16 * ks + 8 * h);
     }
 
     // ---- staging (pipelined: K runs ONE TILE AHEAD of V) -----------------------------------
@@ -213,21 +209,18 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[z][eb][i] = 0.f;
 
-    // Deferred-max online softmax.  m2 is the exponent REFERENCE (log2 units, per query row, shared
-    // by lanes r and r+32); -m2 is the INITIAL ACCUMULATOR of the QK^T MFMA chain (`cinit`, 16 equal
-    // registers), so the accumulators hold S' = S - m2 and P = exp2(S') costs one v_exp and nothing
-    // else.  The reference is raised only when a row's max outgrows it by more than kThr (then
-    // P <= 2^kThr: exact for the fp32 accumulation, inside fp16/bf16 range), or adopted exactly at
-    // the row's first visible key.  mt is the TRUE running row max, kept because the residual
-    // contract wants it (ms = row max, src/attention.jl:128).
+    // Deferred-max online softmax.  m2 is the exponent REFERENCE (log2 units, per query row, shared by lanes r and
+    // r+32): P = exp2(s*c2 - m2).  It is raised only when a row's max outgrows it by more than kThr (then
+    // P <= 2^kThr: exact for the fp32 accumulation, inside fp16/bf16 range).  mt is the TRUE running row max, kept
+    // because the residual contract wants it (ms = row max, src/attention.jl:128).
     constexpr float kThr = 8.0f;
     float m2[QB], mt[QB], lsum[QB];
-    f32x16 cinit[QB], lacc[QB];
+    f32x16 lacc[QB];
 #pragma unroll
     for (int z = 0; z < QB; ++z) {
-        m2[z] = 0.f; mt[z] = -INFINITY; lsum[z] = 0.f;
+        m2[z] = -INFINITY; mt[z] = -INFINITY; lsum[z] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { cinit[z][i] = 0.f; lacc[z][i] = 0.f; }
+        for (int i = 0; i < 16; ++i) lacc[z][i] = 0.f;
     }
     frag_t ones;
 #pragma unroll
@@ -255,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
 #endif
         }
     };
-    // ---- X(t): S'^T = K Q^T - m2 for kv tile t, all query blocks (MFMA) ----------------------
+    // ---- X(t): S^T = K Q^T for kv tile t (raw units), all query blocks (MFMA) --------------------
     auto qk_tile = [&](const char* kimg, const frag_t (&kf)[PFK > 0 ? PFK : 1], f32x16 (&s)[QB][KB]) {
 #if NNOP_V_SETPRIO
         __builtin_amdgcn_s_setprio(1);
@@ -270,10 +263,13 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
                 else a = KImg::read_row_frag(kimg, 32 * kb + r, h, ks);
 #pragma unroll
                 for (int z = 0; z < QB; ++z) {
+                    if (ks == 0) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) s[z][kb][i] = 0.f;
+                    }
 #if NNOP_ABL != 4
-                    s[z][kb] = mma16<T>(a, qf[z][ks], ks == 0 ? cinit[z] : s[z][kb]);
+                    s[z][kb] = mma16<T>(a, qf[z][ks], s[z][kb]);
 #else
-                    if (ks == 0) s[z][kb] = cinit[z];
                     s[z][kb][ks] += (float)a[0];
 #endif
                 }
@@ -300,8 +296,8 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
     auto tile_needs_mask = [&](int t, uint64_t valid) {
         return kGeneral && (valid != kFull || (p.causal && t * BK + BK - 1 > q0w));
     };
-    // mask (-> -inf) / bias tile t of query block z in place and return max(S') over the row (both
-    // halves): the row max relative to the reference the tile was computed against.
+    // mask (-> -inf) / bias tile t of query block z in place and return its row max in log2 units (both halves).
+    // Plain / masked: logits stay in raw units; kPair: they become log2 units (s*c2 + pair*log2e).
     auto finish_x = [&](auto masked, int z, f32x16 (&s)[KB], int t, uint64_t valid) -> float {
         constexpr bool MASKED = decltype(masked)::value;
         const int k0 = t * BK;
@@ -321,6 +317,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
                     }
                     float x = s[kb][i];
                     if constexpr (kPair) {
+                        x *= c2;
                         const int key = k0 + 32 * kb + lr + 4 * h;
                         if (ok && qi[z] < p.QL && key < p.KL) {
                             const size_t po = (((size_t)b * p.KL + key) * p.QL + qi[z]) * p.QH + qh;
@@ -341,7 +338,9 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
 #if NNOP_ABL == 8
         return s[0][0];
 #endif
-        return half_swap_max(fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3])));
+        float mx = fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3]));
+        if constexpr (!kPair) mx *= c2;
+        return half_swap_max(mx);
     };
     auto finish_all = [&](auto masked, f32x16 (&s)[QB][KB], float (&mx)[QB], int t, uint64_t valid) {
 #pragma unroll
@@ -350,11 +349,13 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
     // Y(t): exp / convert / O^T += V^T P^T (+ row sums) for tile t, one 16-key step at a time so
     // that the exps of step kk+1 sit beside the MFMAs of step kk; V fragments shared by the blocks.
     auto softmax_pv = [&](f32x16 (&s)[QB][KB], const char* vimg, const frag_t (&vfp)[PFV > 0 ? PFV : 1]) {
-        float lp[QB][4];
+        float lp[QB][4], msub[QB];
 #pragma unroll
-        for (int z = 0; z < QB; ++z)
+        for (int z = 0; z < QB; ++z) {
+            msub[z] = (kGeneral && m2[z] == -INFINITY) ? 0.f : m2[z];     // a row that has seen no key yet: P = 0
 #pragma unroll
             for (int c = 0; c < 4; ++c) lp[z][c] = 0.f;
+        }
         const char* vb = vimg + vbase;
 #pragma unroll
         for (int kk = 0; kk < 2 * KB; ++kk) {
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
 #if NNOP_ABL != 2
-                    s[z][kb][i0 + j] = fast_exp2(s[z][kb][i0 + j]);
+                    if constexpr (kPair) s[z][kb][i0 + j] = fast_exp2(s[z][kb][i0 + j] - msub[z]);
+                    else s[z][kb][i0 + j] = fast_exp2(__builtin_fmaf(s[z][kb][i0 + j], c2, -msub[z]));
 #endif
                     if constexpr (!kMfmaSum) lp[z][j & 3] += s[z][kb][i0 + j];
                 }
@@ -397,25 +399,22 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
             for (int z = 0; z < QB; ++z) lsum[z] += (lp[z][0] + lp[z][1]) + (lp[z][2] + lp[z][3]);
         }
     };
-    // Top of interval t: `sc` holds S'(t) relative to the current reference m2 and `mxr` its row
-    // max.  Rare path: some row's max outgrew the reference by > kThr, or a row meets its first
-    // visible key -> move the reference.  Everything at the old reference is shifted exactly once:
-    // O, l (accumulated so far), the not-yet-exponentiated S'(t), and the MFMA initial accumulator.
-    auto rescale = [&](f32x16 (&sc)[QB][KB], const float (&mxr)[QB]) {
+    // Before tile t is exponentiated: `mxr` is its row max (log2 units).  Rare path: some row's max outgrew the
+    // reference by > kThr (always at a row's first visible key, m2 = -inf) -> raise the reference.  Everything
+    // accumulated at the old reference (O, l) is scaled exactly once; tile t has not been exponentiated yet.
+    auto rescale = [&](f32x16 (&)[QB][KB], const float (&mxr)[QB]) {
         bool any = false;
-        bool first[QB];
 #pragma unroll
         for (int z = 0; z < QB; ++z) {
-            first[z] = (mt[z] == -INFINITY) && (mxr[z] != -INFINITY);
-            mt[z] = fmaxf(mt[z], m2[z] + mxr[z]);
-            any = any || (mxr[z] > kThr) || first[z];
+            mt[z] = fmaxf(mt[z], mxr[z]);
+            any = any || (mxr[z] > m2[z] + kThr);
         }
         if (__any(any)) {
 #pragma unroll
             for (int z = 0; z < QB; ++z) {
-                const float d = first[z] ? mxr[z] : (mxr[z] > kThr ? mxr[z] : 0.f);
-                const float dd = (d == -INFINITY) ? 0.f : d;          // reference moves by dd (log2 units)
-                const float alpha = first[z] ? 1.f : fast_exp2(-dd);   // nothing accumulated before `first`
+                const bool up = mxr[z] > m2[z] + kThr;
+                const float mn = up ? mxr[z] : m2[z];
+                const float alpha = up ? fast_exp2(m2[z] - mn) : 1.f;      // m2 = -inf -> 0 (nothing accumulated yet)
 #pragma unroll
                 for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
@@ -426,13 +425,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
                 } else {
                     lsum[z] *= alpha;
                 }
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) sc[z][kb][i] -= dd;
-                m2[z] += dd;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) cinit[z][i] = -m2[z];
+                m2[z] = mn;
             }
         }
     };
@@ -614,7 +607,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
                 const T m_t = from_f32<T>(m_nat);
                 const float m_back = to_f32(m_t);
                 float l_out = ltot;                        // sum exp2(x - m2) -> sum exp(s - ms)
-                if (mt[z] != -INFINITY) l_out = ltot * fast_exp2(m2[z] - m_back * kLog2e);
+                if (mt[z] != -INFINITY) l_out = ltot * fast_exp2(m2[z] - m_back * kLog2e);   // both finite here
                 ((T*)p.ms)[so] = m_t;
                 ((T*)p.ls)[so] = from_f32<T>(l_out);
             }

@@ -1,0 +1,71 @@
+"""GPU parity on edge shapes the reference's grids do not reach: single query / single key, QL != KL with
+causal (top-left aligned), one KV head shared by all query heads, lengths around the tile sizes (32, 64, 128, 224,
+256), batch/head = 1, E at both ends of the supported range."""
+import pytest
+import torch
+
+from util import make_inputs, oracle_fwd, oracle_bwd, assert_close
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # B, QH, KH, QL, KL
+    (1, 1, 1, 1, 1), (1, 1, 1, 1, 77), (1, 1, 1, 77, 1), (2, 3, 1, 5, 3), (1, 2, 2, 33, 31),
+    (1, 1, 1, 64, 64), (1, 1, 1, 65, 63), (2, 2, 1, 129, 127), (1, 4, 2, 225, 223), (1, 1, 1, 257, 449),
+    (1, 1, 1, 31, 300), (1, 8, 1, 96, 160),
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("E", [16, 128])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("B,QH,KH,QL,KL", SHAPES)
+def test_edge_shapes_fwd_bwd(pkg, dev, dt, E, causal, B, QH, KH, QL, KL):
+    d = make_inputs(41, B, QH, KH, QL, KL, E, dt, dev)
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=causal)
+    dq, dk, dv, _ = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=causal)
+    torch.cuda.synchronize()
+    o_ref, ms_ref, _ = oracle_fwd(d, causal)
+    rq, rk, rv, _ = oracle_bwd(d, causal)
+    assert_close("o", o, o_ref, dt)
+    assert_close("ms", ms, ms_ref, dt)
+    sc = 1.0 if dt == "f32" else 2.0
+    assert_close("dq", dq, rq, dt, sc, floor=True)
+    assert_close("dk", dk, rk, dt, sc, floor=True)
+    assert_close("dv", dv, rv, dt, sc, floor=True)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+def test_adversarial_logits_force_the_rescale_path(pkg, dev, dt):
+    """Deferred-max softmax: spike single (query, key) pairs so that a row's max jumps far past the 2^8 threshold in
+    the middle of the key sweep, in different tiles for different rows, and make some rows extremely negative
+    (reference max adopted at the first visible key).  A rescale bug shows up as O(0.1) errors (no NaN)."""
+    B, H, L, E = 1, 2, 640, 64
+    d = make_inputs(43, B, H, H, L, L, E, dt, dev)
+    q, k = d["q"].float(), d["k"].float()
+    for row, key, gain in [(5, 70, 9.0), (5, 400, 20.0), (100, 639, 30.0), (333, 200, 14.0), (600, 3, 25.0)]:
+        k[0, :, key] = q[0, :, row] * gain / q[0, :, row].norm(dim=-1, keepdim=True) * (E ** 0.5) / 3
+    q[0, 1, 50:60] *= 40.0                      # huge logits, both signs
+    k[0, 1, :5] = -k[0, 1, :5].abs() * 3
+    d["q"], d["k"] = q.to(d["v"].dtype), k.to(d["v"].dtype)
+    for causal in (False, True):
+        o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=causal)
+        g = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=causal)
+        torch.cuda.synchronize()
+        o_ref, ms_ref, ls_ref = oracle_fwd(d, causal)
+        assert torch.isfinite(o.float()).all()
+        assert_close("o", o, o_ref, dt, 2.0)
+        assert_close("ms", ms, ms_ref, dt, 2.0)
+        rq, rk, rv, _ = oracle_bwd(d, causal)
+        if dt == "f32":
+            assert_close("dq", g[0], rq, dt, 2.0)
+            assert_close("dk", g[1], rk, dt, 2.0)
+            assert_close("dv", g[2], rv, dt, 2.0)
+        else:
+            # 16-bit: dS is rounded to T before the dK / dQ MFMAs, and the rows scaled by 40 amplify that rounding
+            # unit element-wise; the gradients are checked norm-wise (measured: bf16 <= 2.1e-2, f16 <= 3.4e-3)
+            import numpy as np
+            for name, got, ref in (("dq", g[0], rq), ("dk", g[1], rk), ("dv", g[2], rv)):
+                x = got.double().cpu().numpy()
+                assert np.isfinite(x).all()
+                assert np.linalg.norm(x - ref) <= (5e-2 if dt == "bf16" else 1e-2) * np.linalg.norm(ref), name

@@ -51,7 +51,12 @@ def oracle_bwd(d, causal):
                                  causal=causal, kpad_mask=mask)
 
 
-def assert_close(name, got, ref, dt, scale=1.0):
+# absolute floor for results dominated by cancellation of O(1) terms (e.g. dS = P (dP - delta) == 0 exactly when a
+# row sees a single key): a few rounding units of the O(1) operands, summed over up to a few hundred rows
+ABS_FLOOR = {"f32": 1e-5, "f16": 1e-2, "bf16": 6e-2}
+
+
+def assert_close(name, got, ref, dt, scale=1.0, floor=False):
     """|got - ref| <= atol + rtol*|ref| element-wise, atol = ATOL_FRAC * max|ref|; plus the
     reference's own norm-wise check (isapprox atol=rtol=1e-3, test/attention_tests.jl:42-48) for f32."""
     g = to64(got) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
@@ -60,12 +65,12 @@ def assert_close(name, got, ref, dt, scale=1.0):
     assert (np.isnan(g) == np.isnan(ref)).all(), f"{name}: NaN pattern differs"
     gz, rz = np.where(both_nan, 0.0, g), np.where(both_nan, 0.0, ref)
     mag = np.abs(rz).max() if rz.size else 0.0
-    tol = scale * (ATOL_FRAC[dt] * mag + RTOL[dt] * np.abs(rz))
+    tol = scale * (ATOL_FRAC[dt] * mag + RTOL[dt] * np.abs(rz)) + (ABS_FLOOR[dt] if floor else 0.0)
     err = np.abs(gz - rz)
     bad = err > tol
     assert not bad.any(), (f"{name} [{dt}]: {bad.sum()} / {bad.size} outside tolerance; "
                            f"max err {err.max():.3e} (max|ref| {mag:.3e})")
-    if dt == "f32":
+    if dt == "f32" and not floor:
         nrm = np.linalg.norm(gz - rz)
         assert nrm <= max(1e-3, 1e-3 * max(np.linalg.norm(gz), np.linalg.norm(rz))), f"{name}: norm-wise 1e-3"
     return float(err.max() / max(mag, 1e-30))
