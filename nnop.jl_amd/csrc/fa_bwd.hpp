@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    const int lin  = xcd_remap((int)blockIdx.x, p.n_wg);
+    const int lin  = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk);      // chunk = one (batch, kv-head)
     const int kblk = lin % p.n_blk;
     const int bk   = lin / p.n_blk;
     const int b    = bk / p.KH;
@@ -176,6 +176,22 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
 
     bool kvalid = key < p.KL;
     if (kGeneral && p.kpad && kvalid) kvalid = p.kpad[(size_t)b * p.KL + key] != 0;
+    if constexpr (kGeneral) {
+        // variable sequence length: a key block with no valid key gets dK = dV = 0 and does no work
+        if (p.kpad && !__syncthreads_or(kvalid ? 1 : 0)) {
+            if (key < p.KL) {
+                f32x16 zero[EB];
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) zero[eb][i] = 0.f;
+                const size_t ro = ((size_t)(b * p.KH + kvh) * p.KL + key) * E;
+                store_acc_row<T, E>((T*)p.dk + ro, zero, 0.f, h);
+                store_acc_row<T, E>((T*)p.dv + ro, zero, 0.f, h);
+            }
+            return;
+        }
+    }
 
     // ---- K, V fragments (B operands: k = embedding, column = key on the lane) ------------------
     frag_t kf[kKVRegs ? KS : 1], vf[kKVRegs ? KS : 1];
@@ -357,12 +373,13 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
 //   S^T [key][q] = K Q^T   (init: nl[q])      dP^T [key][q] = V dO^T   (init: -delta[q])
 //   dQ^T += K^T dS^T : A = K columns (LDS transposed read), B = dS^T straight from accumulators
 // -------------------------------------------------------------------------------------------------
+constexpr int kMaxMaskTilesBwd = 1024;       // key padding: one 64-bit validity word per kv tile (see fa_fwd.hpp)
 template <typename T, int E, int NW, int BK>
 constexpr int fa_bwd_dq_lds_bytes() {
     constexpr bool qdo_regs = E <= (sizeof(T) == 2 ? 64 : 32);
     constexpr int nbuf = fa_bwd_single<T, E, NW>() ? 1 : 2;
     return (qdo_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) +
-           nbuf * (BwdImgs<T, E>::both(BK) + RowImg<T, E>::bytes(BK));
+           nbuf * (BwdImgs<T, E>::both(BK) + RowImg<T, E>::bytes(BK)) + 8 * kMaxMaskTilesBwd;   // + validity words
 }
 
 template <typename T, int E, int NW, int BK, int MODE>
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    int lin = xcd_remap((int)blockIdx.x, p.n_wg);
+    int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk * (p.QH / p.KH));
     int qblk = lin % p.n_blk;
     const int bh = lin / p.n_blk;
     if (p.causal) qblk = p.n_blk - 1 - qblk;
@@ -413,6 +430,20 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         if (q_last > p.QL - 1) q_last = p.QL - 1;
         const int t_c = q_last / BK + 1;
         if (t_c < n_tiles) n_tiles = t_c;
+    }
+
+    if constexpr (kGeneral) {
+        if (mp) {
+            // variable sequence length: validity words in LDS + stop after the tile holding the last valid key (as the
+            // forward does); no valid key at all -> 0 tiles -> dQ = 0
+            uint64_t* vbits = reinterpret_cast<uint64_t*>(smem + (fa_bwd_dq_lds_bytes<T, E, NW, BK>() - 8 * kMaxMaskTilesBwd));
+            int* slot = reinterpret_cast<int*>(smem);
+            const int nk = n_tiles * BK < p.KL ? n_tiles * BK : p.KL;
+            const int last = kpad_scan(mp, p.KL, nk, vbits, kMaxMaskTilesBwd, slot, tid, NT);
+            const int t_m = last / BK + 1;
+            if (t_m < n_tiles) n_tiles = t_m;
+            __syncthreads();                                   // the slot is reused by the LDS images below
+        }
     }
 
     const float nlq = qi < p.QL ? p.nl[(size_t)bh * p.QL + qi] : -INFINITY;
@@ -454,8 +485,10 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         for (int i = 0; i < 16; ++i) dqa[eb][i] = 0.f;
     const int cbase = Col::lane_base(lane);
 
-    stage_load(0);
-    stage_write(bufs);
+    if (n_tiles > 0) {
+        stage_load(0);
+        stage_write(bufs);
+    }
     if constexpr (kQRegs) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { landed(qf[ks]); landed(dof[ks]); }
@@ -480,9 +513,14 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             if (BK < 64) valid = (1ull << BK) - 1ull;
             if (k0 + BK > p.KL) valid &= (p.KL - k0 >= 64) ? ~0ull : ((1ull << (p.KL - k0)) - 1ull);
             if (mp) {
-                const int kk = k0 + lane;
-                const bool lv = (lane < BK && kk < p.KL) ? (mp[kk] != 0) : false;
-                valid &= __ballot(lv);
+                if ((t * BK) >> 6 < kMaxMaskTilesBwd) {
+                    valid &= kpad_tile_bits<BK>(reinterpret_cast<const uint64_t*>(
+                        smem + (fa_bwd_dq_lds_bytes<T, E, NW, BK>() - 8 * kMaxMaskTilesBwd)), t);
+                } else {
+                    const int kk = k0 + lane;
+                    const bool lv = (lane < BK && kk < p.KL) ? (mp[kk] != 0) : false;
+                    valid &= __ballot(lv);
+                }
             }
             if (valid == 0ull) skip = true;
             need_mask = (valid != ((BK < 64) ? ((1ull << BK) - 1ull) : ~0ull)) ||

@@ -263,6 +263,48 @@ template <typename T, int E, int ROWS, int NT> struct Stager {
     }
 };
 
+// ----------------------------------------------------------------------------------------
+// Key-padding mask -> LDS.  ONE pass over a batch's mask row [0, nkeys): every thread turns 16 mask bytes
+// (one 16-byte load when the row is 16-byte aligned) into a 16-bit piece of the per-64-key validity words
+// `words` (so word w covers keys 64w..64w+63) and tracks the last valid key.  Returns that index (-1: none).
+// All threads of the workgroup must call it (two barriers inside).
+// ----------------------------------------------------------------------------------------
+NNOP_DEV int kpad_scan(const uint8_t* __restrict__ mp, int KL, int nkeys, uint64_t* words, int max_words,
+                       int* slot, int tid, int nthreads) {
+    if (tid == 0) *slot = -1;
+    __syncthreads();
+    uint16_t* w16 = reinterpret_cast<uint16_t*>(words);
+    const bool aligned = (reinterpret_cast<uintptr_t>(mp) & 15) == 0;
+    const int nround = (nkeys + 63) & ~63;                 // whole words get written (tail bits = 0)
+    int last = -1;
+    for (int c = tid; c * 16 < nround; c += nthreads) {
+        const int k0 = c * 16;
+        uint32_t bits = 0;
+        if (aligned && k0 + 16 <= KL) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(mp + k0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bits |= (((v[j >> 2] >> (8 * (j & 3))) & 0xffu) != 0u ? 1u : 0u) << j;
+        } else {
+            for (int j = 0; j < 16; ++j)
+                if (k0 + j < KL && mp[k0 + j] != 0) bits |= 1u << j;
+        }
+        if (k0 + 16 > nkeys) bits &= (k0 < nkeys) ? ((1u << (nkeys - k0)) - 1u) : 0u;
+        if (c < 4 * max_words) w16[c] = (uint16_t)bits;
+        if (bits) last = k0 + 31 - __builtin_clz(bits);
+    }
+    if (last >= 0) atomicMax(slot, last);
+    __syncthreads();
+    return *slot;
+}
+// validity bits of the BK keys of tile t (BK = 32 or 64), wave-uniform, from the words built by kpad_scan
+template <int BK> NNOP_DEV uint64_t kpad_tile_bits(const uint64_t* words, int t) {
+    const uint64_t w = words[(t * BK) >> 6];
+    const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)w);
+    if constexpr (BK == 64) return u;
+    else return (u >> ((t * BK) & 63)) & ((1ull << BK) - 1ull);
+}
+
 // XCD-aware, bijective remap of a linear workgroup id: workgroups b and b+8 share an XCD
 // (observed round-robin dispatch; a speed assumption only, never correctness), so give each
 // XCD one contiguous span of the logical tile order -> neighbouring tiles (same K/V) share
@@ -270,6 +312,17 @@ template <typename T, int E, int ROWS, int NT> struct Stager {
 NNOP_DEV int xcd_remap(int id, int n) {
     const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+// Same purpose, finer grain: the grid is `n / chunk` chunks of `chunk` consecutive tiles that share their K/V (all
+// q-blocks of the q-heads of one (batch, kv-head)); chunks are dealt round-robin to the 8 XCDs, so every XCD gets
+// chunks of every batch.  One contiguous eighth per XCD (xcd_remap) is badly unbalanced when the work per batch
+// differs (variable sequence lengths: measured 1.4x between XCDs at BASELINE config 4).  Needs (n / chunk) % 8 == 0;
+// otherwise falls back to xcd_remap.
+NNOP_DEV int xcd_remap_chunked(int id, int n, int chunk) {
+    const int n_chunks = n / chunk;
+    if (chunk <= 0 || n_chunks * chunk != n || (n_chunks & 7) != 0) return xcd_remap(id, n);
+    const int x = id & 7, s = id >> 3;
+    return ((s / chunk) * 8 + x) * chunk + (s % chunk);
 }
 
 }  // namespace nnop

@@ -59,6 +59,9 @@
 
 namespace nnop {
 
+// key padding: one 64-bit validity word per 64 keys is kept in LDS for up to this many words (64K keys)
+constexpr int kMaxMaskTiles = 1024;
+
 struct FwdParams {
     void*       o;
     void*       ms;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
     }
 
     // ---- which (batch, q-head, q-block) -------------------------------------------------
-    int lin = xcd_remap((int)blockIdx.x, p.n_wg);
+    int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_qblk * (p.QH / p.KH));
     int qblk = lin % p.n_qblk;
     const int bh = lin / p.n_qblk;
     if (p.causal) qblk = p.n_qblk - 1 - qblk;              // heaviest q-blocks first
@@ -156,16 +159,13 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
             if (t_c < n_tiles) n_tiles = t_c;
         }
         if (mp) {
-            // variable sequence length: stop after the tile holding the last valid key
+            // variable sequence length: one pass over the mask row builds the per-64-key validity words in LDS and
+            // finds the last valid key; the walk stops after the tile holding it (none -> 0 tiles -> NaN rows)
+            uint64_t* vbits = reinterpret_cast<uint64_t*>(smem + 2 * KBYTES + 2 * VBYTES + 16);
             int* slot = reinterpret_cast<int*>(smem + 2 * KBYTES + 2 * VBYTES);
-            if (tid == 0) *slot = -1;
-            __syncthreads();
-            int last = -1;
-            for (int i = tid; i < n_tiles * BK && i < p.KL; i += NT)
-                if (mp[i]) last = i;
-            if (last >= 0) atomicMax(slot, last);
-            __syncthreads();
-            const int t_m = *slot / BK + 1;                    // *slot == -1 -> 0 tiles -> NaN rows
+            const int nk = n_tiles * BK < p.KL ? n_tiles * BK : p.KL;
+            const int last = kpad_scan(mp, p.KL, nk, vbits, kMaxMaskTiles, slot, tid, NT);
+            const int t_m = last / BK + 1;
             if (t_m < n_tiles) n_tiles = t_m;
         }
     }
@@ -286,9 +286,13 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
             const int k0 = t * BK;
             if (k0 + BK > p.KL) valid &= (p.KL - k0 >= 64) ? ~0ull : ((1ull << (p.KL - k0)) - 1ull);
             if (mp) {
-                const int kk = k0 + lane;
-                const bool lv = (lane < BK && kk < p.KL) ? (mp[kk] != 0) : false;
-                valid &= __ballot(lv);
+                if ((t * BK) >> 6 < kMaxMaskTiles) {
+                    valid &= kpad_tile_bits<BK>(reinterpret_cast<const uint64_t*>(smem + 2 * KBYTES + 2 * VBYTES + 16), t);
+                } else {                                   // sequences beyond 64K keys: read the mask per tile
+                    const int kk = k0 + lane;
+                    const bool lv = (lane < BK && kk < p.KL) ? (mp[kk] != 0) : false;
+                    valid &= __ballot(lv);
+                }
             }
         }
         return valid;
@@ -615,9 +619,10 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
     }
 }
 
-// LDS bytes the kernel needs (K ring of 2 + V ring of 2 + one scratch slot).
+// LDS bytes the kernel needs: K ring of 2 + V ring of 2 + one scratch slot + (key padding) one 64-bit validity
+// word per kv tile for up to kMaxMaskTiles tiles (longer sequences fall back to reading the mask per tile).
 template <typename T, int E, int BK> constexpr int fa_fwd_lds_bytes() {
-    return 2 * (RowImg<T, E>::bytes(BK) + ColImg<T, E>::bytes(BK)) + 16;
+    return 2 * (RowImg<T, E>::bytes(BK) + ColImg<T, E>::bytes(BK)) + 16 + 8 * kMaxMaskTiles;
 }
 
 }  // namespace nnop

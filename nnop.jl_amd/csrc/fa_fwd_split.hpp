@@ -46,7 +46,7 @@ __global__ __launch_bounds__(1024) void fa_fwd_split_kernel(const FwdParams p) {
     const int grp = wave >> 3, w8 = wave & 7;
     const int r = lane & 31, h = lane >> 5;
 
-    const int lin = xcd_remap((int)blockIdx.x, p.n_wg);
+    const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_qblk * (p.QH / p.KH));
     const int qblk = lin % p.n_qblk;
     const int bh = lin / p.n_qblk;
     const int b = bh / p.QH, qh = bh - b * p.QH;
