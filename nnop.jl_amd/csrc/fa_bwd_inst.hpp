@@ -21,22 +21,13 @@ template <typename T, int E> struct BwdCfg {
     static constexpr int BK    = (E > 64) ? 32 : 64;
 };
 
-template <typename K> static int set_lds(K kern, int lds) {
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return NNOP_ERR_HIP;
-        }
-    }
-    return NNOP_OK;
-}
-
 template <typename T, int E, int NW, int BQ, int MODE>
 static int launch_dkdv(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
     constexpr int lds = fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = fa_bwd_dkdv_kernel<T, E, NW, BQ, MODE>;
-    if (set_lds(kern, lds) != NNOP_OK) return NNOP_ERR_HIP;
+    static unsigned long long lds_done = 0;
+    if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
     BwdParams pk = p;
     pk.n_blk = (d.kl + 32 * NW - 1) / (32 * NW);
     const long long n_wg = (long long)pk.n_blk * d.kh * d.batch;
@@ -51,7 +42,8 @@ static int launch_dq(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
     constexpr int lds = fa_bwd_dq_lds_bytes<T, E, NW, BK>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = fa_bwd_dq_kernel<T, E, NW, BK, MODE>;
-    if (set_lds(kern, lds) != NNOP_OK) return NNOP_ERR_HIP;
+    static unsigned long long lds_done = 0;
+    if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
     BwdParams pq = p;
     pq.n_blk = (d.ql + 32 * NW - 1) / (32 * NW);
     const long long n_wg = (long long)pq.n_blk * d.qh * d.batch;

@@ -21,12 +21,8 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     constexpr int lds = fa_fwd_lds_bytes<T, E, BK>();
     static_assert(lds <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
     auto kern = fa_fwd_kernel<T, E, NW, BK, MODE, QB>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return NNOP_ERR_HIP;
-        }
-    }
+    static unsigned long long lds_done = 0;
+    if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
     FwdParams p;
     p.o = a.o; p.ms = a.ms; p.ls = a.ls;
     p.q = a.q; p.k = a.k; p.v = a.v; p.pair = a.pair; p.kpad = a.kpad;
@@ -50,12 +46,8 @@ static int launch_fwd_split(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t
     constexpr int lds = fa_fwd_split_lds_bytes<T, E>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = fa_fwd_split_kernel<T, E>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return NNOP_ERR_HIP;
-        }
-    }
+    static unsigned long long lds_done = 0;
+    if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
     FwdParams p;
     p.o = a.o; p.ms = a.ms; p.ls = a.ls;
     p.q = a.q; p.k = a.k; p.v = a.v; p.pair = nullptr; p.kpad = nullptr;

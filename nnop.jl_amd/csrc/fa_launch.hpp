@@ -36,4 +36,21 @@ inline size_t bwd_workspace_bytes(const nnop_fa_desc& d) {
 // Optional tuning override (read-only environment): workgroup waves for the forward.
 int env_int(const char* name, int dflt);
 
+// Kernels that need more than 64 KiB of dynamic LDS must opt in once per (kernel, device).  `done` is a per-kernel
+// static bitmap (one bit per device ordinal < 64); setting the attribute twice is harmless, so a benign race between
+// host threads only costs a redundant call.
+template <typename K> inline int ensure_dynamic_lds(K kern, int lds_bytes, unsigned long long* done) {
+    if (lds_bytes <= 64 * 1024) return NNOP_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return NNOP_ERR_HIP; }
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (dev < 64 && (__atomic_load_n(done, __ATOMIC_RELAXED) & bit)) return NNOP_OK;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return NNOP_ERR_HIP;
+    }
+    if (dev < 64) __atomic_fetch_or(done, bit, __ATOMIC_RELAXED);
+    return NNOP_OK;
+}
+
 }  // namespace nnop
