@@ -70,14 +70,17 @@ def cpu_baseline(E, L, H, B):
     q, k, v, do = (rng.standard_normal((B, H, L, E), dtype=np.float32) for _ in range(4))
     naive_attention_f32(q[:1, :1], k[:1, :1], v[:1, :1])          # warm BLAS threads
     ts = []
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.perf_counter()
         naive_attention_f32(q, k, v)
         ts.append(time.perf_counter() - t0)
     t_fwd = statistics.median(ts)
-    t0 = time.perf_counter()
-    naive_attention_f32_fwd_bwd(q, k, v, do)
-    t_fb = time.perf_counter() - t0
+    tb = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        naive_attention_f32_fwd_bwd(q, k, v, do)
+        tb.append(time.perf_counter() - t0)
+    t_fb = statistics.median(tb)
     f = attention_flops(E, L, L, H, B, causal=False)
     model = ""
     try:
@@ -89,8 +92,8 @@ def cpu_baseline(E, L, H, B):
         pass
     return {
         "value": round(f / t_fwd / 1e12, 4), "unit": "TFLOP/s", "cores": int(threads), "kind": "port",
-        "sample": f"full C1 workload (fp32 E={E} L={L} H={H} B={B}, 1 GiB score tensor): forward median of 3 "
-                  f"runs = {t_fwd:.2f} s; forward+backward 1 run = {t_fb:.2f} s",
+        "sample": f"full C1 workload (fp32 E={E} L={L} H={H} B={B}, 1 GiB score tensor): forward median of 5 "
+                  f"runs = {t_fwd:.2f} s; forward+backward median of 3 runs = {t_fb:.2f} s",
         "fwd_s": round(t_fwd, 3), "fwd_bwd_s": round(t_fb, 3),
         "fwd_bwd_tflops": round(f * 3.5 / t_fb / 1e12, 4),
         "host_cpus": os.cpu_count(), "cpu_model": model,
