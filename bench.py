@@ -40,6 +40,7 @@ CONFIGS = {
     "c1gpu": ("f32", 64, 4096, 4, 4, 4, False),         # fp32 twin of configs[0] on the GPU
     "c3": ("bf16", 128, 8192, 32, 32, 8, True),          # configs[2]
     "c4": ("f16", 128, 4096, 32, 8, 16, False),          # configs[3]: GQA 32/8, variable sequence length
+    "c5": ("bf16", 128, 16384, 32, 32, 8, True),         # configs[4]: ONE GPU's shard (B = 64 / 8) of the 8-GPU config
 }
 # C4 lengths: numpy.random.default_rng(0).integers(1024, 4097, size=16)
 C4_LENS = [3637, 2981, 2594, 1853, 1969, 1149, 1255, 1074, 1562, 3523, 3019, 3828, 2571, 2888, 4007, 3265]

@@ -304,32 +304,33 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
 
             // P = exp2(c*S'), dS = P*dP'   (rows = queries in registers, key on the lane)
             const bool diag = kGeneral && p.causal && (q0 < kw0 + 31);
+            // pair / dpair [B][KL][QL][QH]: one 64-bit base per (q-block, lane); rows are QH elements apart
+            // (dpair is written by the dQ kernel, where the lane axis is the tensor's contiguous direction)
+            const T* pbase = nullptr;
+            int qmax = 0;
+            if constexpr (kPair) {
+                pbase = (const T*)p.pair + (((size_t)b * p.KL + key_c) * p.QL + q0) * p.QH + qh;
+                qmax = p.QL - 1 - q0;                                      // last in-range local query row
+            }
             f32x16 ds;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float x = s[i] * c2;
-                const int qrow_i = q0 + acc_row(i, h);
+                const int lrow = acc_row(i, h);
+                const int qrow_i = q0 + lrow;
                 bool ok = true;
                 if constexpr (kGeneral) {
                     ok = kvalid;
                     if (diag) ok = ok && (qrow_i >= key);
                     if constexpr (kPair) {
-                        if (ok && qrow_i < p.QL) {
-                            const size_t po = (((size_t)b * p.KL + key) * p.QL + qrow_i) * p.QH + qh;
-                            x += to_f32(((const T*)p.pair)[po]) * kLog2e;
-                        }
+                        const int lr = lrow < qmax ? lrow : qmax;            // clamped: always inside the tensor
+                        x += to_f32(pbase[lr * p.QH]) * kLog2e;
                     }
                 }
                 float pr = fast_exp2(x);
                 if constexpr (kGeneral) pr = ok ? pr : 0.f;
                 s[i] = pr;
                 ds[i] = pr * dp[i];
-                if constexpr (kPair) {
-                    if (key < p.KL && qrow_i < p.QL) {
-                        const size_t po = (((size_t)b * p.KL + key) * p.QL + qrow_i) * p.QH + qh;
-                        ((T*)p.dpair)[po] = from_f32<T>(ds[i]);
-                    }
-                }
             }
             const frag_t p0 = acc_frag<T, 0>(s), p1 = acc_frag<T, 1>(s);
             const frag_t d0 = acc_frag<T, 0>(ds), d1 = acc_frag<T, 1>(ds);
@@ -549,6 +550,16 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                 }
                 const uint32_t w = (uint32_t)(valid >> (32 * kb + 4 * h));
                 const int lim = qi - k0 - 32 * kb - 4 * h;
+                const T* pbase = nullptr;
+                T* dpbase = nullptr;
+                int kstride = 0, kmax = 0;
+                if constexpr (kPair) {
+                    kstride = p.QL * p.QH;
+                    kmax = p.KL - 1 - k0;
+                    const size_t po = (((size_t)b * p.KL + k0) * p.QL + qi_c) * p.QH + qh;
+                    pbase = (const T*)p.pair + po;
+                    dpbase = (T*)p.dpair + po;
+                }
                 f32x16 ds;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -560,17 +571,20 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                             ok = (w >> lr) & 1u;
                             if (p.causal) ok = ok && (lr <= lim);
                             if constexpr (kPair) {
-                                if (ok && qi < p.QL) {
-                                    const int kkey = k0 + 32 * kb + lr + 4 * h;
-                                    const size_t po = (((size_t)b * p.KL + kkey) * p.QL + qi) * p.QH + qh;
-                                    x += to_f32(((const T*)p.pair)[po]) * kLog2e;
-                                }
+                                int kl = 32 * kb + lr + 4 * h;
+                                kl = kl < kmax ? kl : kmax;
+                                x += to_f32(pbase[kl * kstride]) * kLog2e;
                             }
                         }
                     }
                     float pr = fast_exp2(x);
                     if constexpr (kGeneral) pr = ok ? pr : 0.f;
                     ds[i] = pr * dp[i];
+                    if constexpr (kPair) {
+                        // dpair = dS (the reference's dS / scale, src/attention_bwd.jl:123-132); lanes = consecutive queries
+                        const int klr = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (klr <= kmax && qi < p.QL) dpbase[klr * kstride] = from_f32<T>(ds[i]);
+                    }
                 }
                 const frag_t d0 = acc_frag<T, 0>(ds), d1 = acc_frag<T, 1>(ds);
 #pragma unroll

@@ -307,6 +307,16 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
         const int k0 = t * BK;
         float mxp[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};      // 4 independent chains
         if constexpr (MASKED || kPair) {
+            // pair bias [B][KL][QL][QH]: one 64-bit base per (tile, lane), 32-bit element offsets, addresses clamped
+            // into the tensor (no divergent branch around the loads), masked-out logits dropped by the select below
+            const T* pbase = nullptr;
+            int kstride = 0, kmax = 0;
+            if constexpr (kPair) {
+                const int qc = qi[z] < p.QL ? qi[z] : p.QL - 1;
+                kstride = p.QL * p.QH;                                      // elements between consecutive keys
+                kmax = p.KL - 1 - k0;                                       // last in-range local key of this tile
+                pbase = (const T*)p.pair + (((size_t)b * p.KL + k0) * p.QL + qc) * p.QH + qh;
+            }
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const uint32_t w = (uint32_t)(valid >> (32 * kb + 4 * h));
@@ -321,12 +331,9 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
                     }
                     float x = s[kb][i];
                     if constexpr (kPair) {
-                        x *= c2;
-                        const int key = k0 + 32 * kb + lr + 4 * h;
-                        if (ok && qi[z] < p.QL && key < p.KL) {
-                            const size_t po = (((size_t)b * p.KL + key) * p.QL + qi[z]) * p.QH + qh;
-                            x += to_f32(((const T*)p.pair)[po]) * kLog2e;
-                        }
+                        int kl = 32 * kb + lr + 4 * h;
+                        kl = kl < kmax ? kl : kmax;
+                        x = __builtin_fmaf(x, c2, to_f32(pbase[kl * kstride]) * kLog2e);
                     }
                     s[kb][i] = ok ? x : -INFINITY;
                     mxp[i & 3] = fmaxf(mxp[i & 3], s[kb][i]);
