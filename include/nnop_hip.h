@@ -124,6 +124,31 @@ int nnop_fa_bwd(const nnop_fa_desc* d,
                 void* workspace, size_t workspace_bytes,
                 nnop_stream_t stream);
 
+/*
+ * Llama rotary embedding: contract of NNop._llama_rope(q, k, cos, sin; bwd)
+ * (src/rope/llama_rope.jl:69-89) + kernel llama_rope! (:24-65).  For every row x of q and of k:
+ *     out[i]       = x[i] * cos[i] - x[i + D/2] * (sin_sign * sin[i])
+ *     out[i + D/2] = x[i + D/2] * cos[i] + x[i] * (sin_sign * sin[i])          i < D/2
+ * with cos, sin indexed by (position, batch) and shared by all heads.  sin_sign = +1: llama_rope;
+ * sin_sign = -1: the pullback ∇llama_rope applied to (dq, dk) (:92).  Out of place (the reference copies q, k and
+ * rotates the copies, :75-76); q_out == q / k_out == k (in place) is allowed.
+ *   q, q_out : [B][QH][L][D]    k, k_out : [B][KH][L][D]    cos, sin : [B][L][D] (only the first D/2 of a row are read)
+ *   dtype: element type of q, k;  cs_dtype: element type of cos, sin -- NNOP_F32 (what LlamaRotaryEmbedding
+ *   returns, :15-22) or the same as dtype.  D must be even.  The arithmetic is fp32, one rounding to T on store.
+ */
+typedef struct nnop_rope_desc {
+    int32_t dtype;     /* nnop_dtype of q, k */
+    int32_t cs_dtype;  /* nnop_dtype of cos, sin */
+    int32_t dim;       /* D  = size(q,1) */
+    int32_t seq;       /* L  = size(q,2) == size(k,2) */
+    int32_t qh;        /* size(q,3) */
+    int32_t kh;        /* size(k,3) */
+    int32_t batch;     /* size(q,4) == size(k,4) */
+} nnop_rope_desc;
+
+int nnop_llama_rope(const nnop_rope_desc* d, void* q_out, void* k_out, const void* q, const void* k,
+                    const void* cos, const void* sin, float sin_sign, nnop_stream_t stream);
+
 /* NNop._shared_memory(::ROCBackend, device_id) (ext/NNopAMDGPUExt.jl:6-9):
  * hipDeviceProp_t.sharedMemPerBlock of `device` (0-based HIP ordinal). */
 int nnop_shared_memory(int device, uint64_t* bytes);
@@ -132,7 +157,7 @@ int nnop_shared_memory(int device, uint64_t* bytes);
 const char* nnop_strerror(int status);
 
 /* ABI version of this header: bumped on any incompatible change. */
-#define NNOP_HIP_ABI_VERSION 1
+#define NNOP_HIP_ABI_VERSION 2
 int nnop_abi_version(void);
 
 #ifdef __cplusplus

@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = (
     "nnop_fa_fwd",
     "nnop_fa_bwd_workspace_bytes",
     "nnop_fa_bwd",
+    "nnop_llama_rope",
     "nnop_shared_memory",
     "nnop_strerror",
     "nnop_abi_version",
@@ -45,6 +46,14 @@ class FaDesc(C.Structure):
         ("dtype", C.c_int32), ("emb", C.c_int32), ("ql", C.c_int32), ("kl", C.c_int32),
         ("qh", C.c_int32), ("kh", C.c_int32), ("batch", C.c_int32), ("causal", C.c_int32),
         ("emb_k", C.c_int32), ("emb_v", C.c_int32), ("kl_v", C.c_int32), ("kh_v", C.c_int32),
+    ]
+
+
+class RopeDesc(C.Structure):
+    """struct nnop_rope_desc"""
+    _fields_ = [
+        ("dtype", C.c_int32), ("cs_dtype", C.c_int32), ("dim", C.c_int32), ("seq", C.c_int32),
+        ("qh", C.c_int32), ("kh", C.c_int32), ("batch", C.c_int32),
     ]
 
 
@@ -73,6 +82,8 @@ def load():
     lib.nnop_fa_bwd.restype = C.c_int
     lib.nnop_fa_bwd.argtypes = [C.POINTER(FaDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                 u8p, vp, C.c_size_t, vp]
+    lib.nnop_llama_rope.restype = C.c_int
+    lib.nnop_llama_rope.argtypes = [C.POINTER(RopeDesc), vp, vp, vp, vp, vp, vp, C.c_float, vp]
     lib.nnop_shared_memory.restype = C.c_int
     lib.nnop_shared_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.nnop_strerror.restype = C.c_char_p

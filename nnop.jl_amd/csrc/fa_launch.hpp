@@ -25,6 +25,10 @@ template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hi
 // One per dtype (fa_bwd_{f32,f16,bf16}.hip).
 template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s);
 
+// rope.hip
+int launch_rope(const nnop_rope_desc& d, void* qo, void* ko, const void* q, const void* k, const void* cos,
+                const void* sin, float sin_sign, hipStream_t s);
+
 // Embedding dims the MFMA kernels are instantiated for.
 inline bool emb_supported(int e) { return e == 16 || e == 32 || e == 64 || e == 128; }
 

@@ -85,6 +85,16 @@ int nnop_fa_fwd(const nnop_fa_desc* d, void* o, void* ms, void* ls, const void* 
     return NNOP_ERR_DTYPE;
 }
 
+int nnop_llama_rope(const nnop_rope_desc* d, void* q_out, void* k_out, const void* q, const void* k,
+                    const void* cos, const void* sin, float sin_sign, nnop_stream_t stream) {
+    if (!d) return NNOP_ERR_NULL;
+    if (d->dtype != NNOP_F32 && d->dtype != NNOP_F16 && d->dtype != NNOP_BF16) return NNOP_ERR_DTYPE;
+    if (d->cs_dtype != NNOP_F32 && d->cs_dtype != d->dtype) return NNOP_ERR_DTYPE;
+    if (d->dim <= 0 || (d->dim & 1) || d->seq <= 0 || d->qh <= 0 || d->kh <= 0 || d->batch <= 0) return NNOP_ERR_SHAPE;
+    if (!q_out || !k_out || !q || !k || !cos || !sin) return NNOP_ERR_NULL;
+    return launch_rope(*d, q_out, k_out, q, k, cos, sin, sin_sign, (hipStream_t)stream);
+}
+
 size_t nnop_fa_bwd_workspace_bytes(const nnop_fa_desc* d) {
     if (check_desc(d) != NNOP_OK) return 0;
     return bwd_workspace_bytes(*d);

@@ -8,6 +8,7 @@
 #   NNop._shared_memory(::ROCBackend, device_id)             ext/NNopAMDGPUExt.jl:6-9
 #   NNop._flash_attention(q,k,v,pair; causal,kpad_mask)       src/attention.jl:133-177   -> (o, ms, ls)
 #   NNop.∇flash_attention(Δ,o,ms,ls,q,k,v,pair; causal,...)   src/attention_bwd.jl:199-275 -> (dq,dk,dv,dpair)
+#   NNop._llama_rope(q, k, cos, sin; bwd)                     src/rope/llama_rope.jl:69-89 -> (q', k')
 #
 # `flash_attention` and the ChainRules `rrule` (src/attention_crc.jl:4-31) call these generically, so
 # `NNop.flash_attention(q, k, v; causal)` and `Zygote.gradient` keep working unchanged.
@@ -109,6 +110,29 @@ function NNop.∇flash_attention(
         devptr(q), devptr(k), devptr(v), devptr(pair), devptr(kpad_mask), devptr(ws), nbytes, hipstream())
     check(st, q, k, v)
     return dq, dk, dv, dp
+end
+
+# struct nnop_rope_desc (include/nnop_hip.h)
+struct RopeDesc
+    dtype::Int32; cs_dtype::Int32; dim::Int32; seq::Int32; qh::Int32; kh::Int32; batch::Int32
+end
+
+# src/rope/llama_rope.jl:69-89.  `llama_rope`, `∇llama_rope` and the rrule (:67, :91-98) call this generically.
+# One pass, out of place: replaces copy(q), copy(k) + the in-place kernel (:75-86).
+function NNop._llama_rope(
+    q::ROCArray{T,4}, k::ROCArray{T,4}, cos::ROCArray{C,3}, sin::ROCArray{C,3}; bwd::Bool,
+) where {T <: HipFloat, C <: HipFloat}
+    head_dim, q_seq, q_heads, batch = size(q)
+    @assert size(k, 1) == head_dim "Head dimension mismatch"    # :72
+    @assert size(k, 2) == q_seq && size(k, 4) == batch          # :73
+    @assert size(cos) == size(sin) == (head_dim, q_seq, batch)
+    d = Ref(RopeDesc(nnop_dtype(T), nnop_dtype(C), head_dim, q_seq, q_heads, size(k, 3), batch))
+    qo, ko = similar(q), similar(k)
+    st = ccall((:nnop_llama_rope, libnnop()), Cint,
+        (Ptr{RopeDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}),
+        d, devptr(qo), devptr(ko), devptr(q), devptr(k), devptr(cos), devptr(sin), bwd ? -1f0 : 1f0, hipstream())
+    st == 0 || error("libnnop_hip: " * unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st)))
+    return qo, ko
 end
 
 end # module
