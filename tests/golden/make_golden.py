@@ -16,6 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle.naive_attention import naive_attention, naive_attention_grads  # noqa: E402
+from oracle.naive_rope import llama_rotary_embedding, naive_llama_rope, pairwise_llama_rope  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -65,7 +66,34 @@ def make_case(seed, B, QH, KH, QL, KL, E, causal, pad, pair):
     return d
 
 
+# Llama RoPE.  name: (seed, B, QH, KH, L, D, position offset)
+ROPE_CASES = {
+    "ref_d16":   (20, 2, 3, 5, 257, 16, 0),        # the reference's test dim (test/rope_tests.jl:22)
+    "gqa_d128":  (21, 2, 8, 2, 131, 128, 1000),
+    "odd_d6":    (22, 1, 2, 1, 40, 6, 7),          # half dim not a multiple of 8: generic path
+}
+
+
+def make_rope_case(seed, B, QH, KH, L, D, off):
+    rng = np.random.default_rng(seed)
+    g = lambda *s: bf16_round(rng.standard_normal(s).astype(np.float32))
+    pos = np.tile(np.arange(L, dtype=np.float32) + off, (B, 1))
+    cos, sin = llama_rotary_embedding(D, pos)                       # fp32 tables, stored as the kernel receives them
+    d = dict(q=g(B, QH, L, D), k=g(B, KH, L, D), dq_out=g(B, QH, L, D), dk_out=g(B, KH, L, D), cos=cos, sin=sin,
+             position_ids=pos)
+    qo, ko = naive_llama_rope(d["q"], d["k"], cos, sin)
+    dq, dk = pairwise_llama_rope(d["dq_out"], d["dk_out"], cos, sin, sin_sign=-1.0)
+    d.update(q_out=qo.astype(np.float32), k_out=ko.astype(np.float32), dq=dq.astype(np.float32), dk=dk.astype(np.float32))
+    return d
+
+
 def main():
+    for name, cfg in ROPE_CASES.items():
+        d = make_rope_case(*cfg)
+        np.savez_compressed(os.path.join(HERE, f"rope_{name}.npz"), **d)
+        print("rope", name, {k: v.shape for k, v in d.items()})
+    if "--rope-only" in sys.argv:
+        return
     for name, cfg in CASES.items():
         d = make_case(*cfg)
         np.savez_compressed(os.path.join(HERE, f"fa_{name}.npz"), **d)

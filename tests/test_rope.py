@@ -100,3 +100,21 @@ def test_rope_host_refuses_cpu_tensors(pkg):
     q = torch.ones(1, 1, 4, 16); cos = torch.ones(1, 4, 16)
     with pytest.raises(pkg.NNopError, match="GPU-only"):
         pkg.llama_rope(q, q, cos=cos, sin=cos)
+
+
+def test_oracle_reproduces_rope_golden_fixtures():
+    """The committed fixtures (tests/golden/rope_*.npz, make_golden.py) are what the oracle computes today."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "rope_*.npz")))
+    assert len(files) >= 3
+    for f in files:
+        g = np.load(f)
+        cos, sin = llama_rotary_embedding(g["q"].shape[-1], g["position_ids"])
+        # libm / SIMD cos of another host may differ in the last ulp of fp32
+        np.testing.assert_allclose(cos, g["cos"], atol=1e-6); np.testing.assert_allclose(sin, g["sin"], atol=1e-6)
+        qo, ko = naive_llama_rope(g["q"], g["k"], g["cos"], g["sin"])
+        np.testing.assert_allclose(qo, g["q_out"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(ko, g["k_out"], rtol=1e-6, atol=1e-7)
+        dq, dk = pairwise_llama_rope(g["dq_out"], g["dk_out"], g["cos"], g["sin"], sin_sign=-1.0)
+        np.testing.assert_allclose(dq, g["dq"], rtol=1e-6, atol=1e-7)

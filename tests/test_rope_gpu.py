@@ -141,3 +141,22 @@ def test_host_checks(pkg):
         pkg.llama_rope(q, k.half(), cos=cos, sin=sin)
     with pytest.raises(TypeError):
         pkg.llama_rope(q, k, cos=cos.half(), sin=sin.half())         # fp32 q with fp16 tables
+
+
+import glob as _glob
+import os as _os
+
+_ROPE_GOLDEN = sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "rope_*.npz")))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("path", _ROPE_GOLDEN, ids=[_os.path.basename(p)[5:-4] for p in _ROPE_GOLDEN])
+def test_rope_golden(pkg, path, dt):
+    """Committed fixtures (bf16-exact inputs, fp64-oracle outputs): forward and pullback in all three dtypes."""
+    g = np.load(path)
+    t = lambda n: torch.tensor(g[n]).to(TORCH_DT[dt]).to(DEV)
+    cos, sin = torch.tensor(g["cos"]).to(DEV), torch.tensor(g["sin"]).to(DEV)
+    qo, ko = pkg._llama_rope(t("q"), t("k"), cos, sin, bwd=False)
+    dq, dk = pkg.grad_llama_rope((t("dq_out"), t("dk_out")), cos, sin)
+    for got, name in ((qo, "q_out"), (ko, "k_out"), (dq, "dq"), (dk, "dk")):
+        _check(got, g[name].astype(np.float64), dt)
