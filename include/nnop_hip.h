@@ -149,6 +149,27 @@ typedef struct nnop_rope_desc {
 int nnop_llama_rope(const nnop_rope_desc* d, void* q_out, void* k_out, const void* q, const void* k,
                     const void* cos, const void* sin, float sin_sign, nnop_stream_t stream);
 
+/*
+ * Online softmax: NNop.online_softmax(x) (src/softmax.jl:60-68, kernel
+ * online_softmax! :19-58, reduction monoid MD / md_reduce :1-16 through @groupreduce, src/groupreduce.jl:13-43) and
+ * its pullback ∇online_softmax(Δ, y) (src/softmax.jl:70-80).
+ *   x, y, dy, dx : [batch][N]  == Julia matrix (N, batch); softmax along N (dims = 1 in Julia).
+ *   y[b][:]  = exp(x[b][:] - max) / sum(exp(x[b][:] - max))
+ *   dx[b][:] = y[b][:] * (dy[b][:] - sum(dy[b][:] * y[b][:]))
+ * One element type T for all arrays (the reference: y = similar(x)); fp32 arithmetic, one rounding on store.
+ * Any N >= 1; rows whose byte length is a multiple of 16 (and up to 16384 fp32 / 32768 16-bit elements) are
+ * held in registers and touch HBM once.
+ */
+typedef struct nnop_softmax_desc {
+    int32_t dtype;   /* nnop_dtype */
+    int32_t n;       /* N = size(x,1) */
+    int64_t batch;   /* size(x,2) */
+} nnop_softmax_desc;
+
+int nnop_online_softmax(const nnop_softmax_desc* d, void* y, const void* x, nnop_stream_t stream);
+int nnop_online_softmax_bwd(const nnop_softmax_desc* d, void* dx, const void* dy, const void* y,
+                            nnop_stream_t stream);
+
 /* NNop._shared_memory(::ROCBackend, device_id) (ext/NNopAMDGPUExt.jl:6-9):
  * hipDeviceProp_t.sharedMemPerBlock of `device` (0-based HIP ordinal). */
 int nnop_shared_memory(int device, uint64_t* bytes);
@@ -157,7 +178,7 @@ int nnop_shared_memory(int device, uint64_t* bytes);
 const char* nnop_strerror(int status);
 
 /* ABI version of this header: bumped on any incompatible change. */
-#define NNOP_HIP_ABI_VERSION 2
+#define NNOP_HIP_ABI_VERSION 3
 int nnop_abi_version(void);
 
 #ifdef __cplusplus

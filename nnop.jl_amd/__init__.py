@@ -12,9 +12,11 @@ The directory name contains a dot, so import it through ``__graft_entry__.load_p
 from .attention import (NNopError, flash_attention, _flash_attention, grad_flash_attention,
                         shared_memory, bwd_workspace_bytes, fa_fwd_into, fa_bwd_into)
 from .rope import LlamaRotaryEmbedding, llama_rope, _llama_rope, grad_llama_rope, llama_rope_into
+from .softmax import online_softmax, grad_online_softmax, online_softmax_into
 from . import _lib, shard
 
 __all__ = ["NNopError", "flash_attention", "_flash_attention", "grad_flash_attention",
            "shared_memory", "bwd_workspace_bytes", "fa_fwd_into", "fa_bwd_into", "LlamaRotaryEmbedding", "llama_rope", "_llama_rope", "grad_llama_rope", "llama_rope_into",
+           "online_softmax", "grad_online_softmax", "online_softmax_into",
            "shard", "_lib"]
 __version__ = "0.1.0"

@@ -13,6 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NNOP_LIB_PATH: development override (timing-only ablation builds); never set in production
 LIB_PATH = os.environ.get("NNOP_LIB_PATH") or os.path.join(_HERE, "lib", "libnnop_hip.so")
 
+# NNOP_HIP_ABI_VERSION of the header this binding was written against; load() refuses another library
+ABI_VERSION = 3
+
 # nnop_dtype (include/nnop_hip.h)
 NNOP_F32, NNOP_F16, NNOP_BF16 = 0, 1, 2
 
@@ -34,6 +37,8 @@ EXPORTED_SYMBOLS = (
     "nnop_fa_bwd_workspace_bytes",
     "nnop_fa_bwd",
     "nnop_llama_rope",
+    "nnop_online_softmax",
+    "nnop_online_softmax_bwd",
     "nnop_shared_memory",
     "nnop_strerror",
     "nnop_abi_version",
@@ -55,6 +60,11 @@ class RopeDesc(C.Structure):
         ("dtype", C.c_int32), ("cs_dtype", C.c_int32), ("dim", C.c_int32), ("seq", C.c_int32),
         ("qh", C.c_int32), ("kh", C.c_int32), ("batch", C.c_int32),
     ]
+
+
+class SoftmaxDesc(C.Structure):
+    """struct nnop_softmax_desc"""
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("batch", C.c_int64)]
 
 
 class NNopLibraryMissing(ImportError):
@@ -84,12 +94,19 @@ def load():
                                 u8p, vp, C.c_size_t, vp]
     lib.nnop_llama_rope.restype = C.c_int
     lib.nnop_llama_rope.argtypes = [C.POINTER(RopeDesc), vp, vp, vp, vp, vp, vp, C.c_float, vp]
+    lib.nnop_online_softmax.restype = C.c_int
+    lib.nnop_online_softmax.argtypes = [C.POINTER(SoftmaxDesc), vp, vp, vp]
+    lib.nnop_online_softmax_bwd.restype = C.c_int
+    lib.nnop_online_softmax_bwd.argtypes = [C.POINTER(SoftmaxDesc), vp, vp, vp, vp]
     lib.nnop_shared_memory.restype = C.c_int
     lib.nnop_shared_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.nnop_strerror.restype = C.c_char_p
     lib.nnop_strerror.argtypes = [C.c_int]
     lib.nnop_abi_version.restype = C.c_int
     lib.nnop_abi_version.argtypes = []
+    if lib.nnop_abi_version() != ABI_VERSION:
+        raise NNopLibraryMissing(f"{LIB_PATH} has ABI version {lib.nnop_abi_version()}, this binding needs "
+                                 f"{ABI_VERSION}: rebuild with `make -C nnop.jl_amd/csrc -j8`")
     _lib = lib
     return lib
 

@@ -29,6 +29,9 @@ template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hi
 int launch_rope(const nnop_rope_desc& d, void* qo, void* ko, const void* q, const void* k, const void* cos,
                 const void* sin, float sin_sign, hipStream_t s);
 
+// softmax.hip (a = x | dy, b = nullptr | y)
+int launch_softmax(const nnop_softmax_desc& d, void* out, const void* a, const void* b, bool bwd, hipStream_t s);
+
 // Embedding dims the MFMA kernels are instantiated for.
 inline bool emb_supported(int e) { return e == 16 || e == 32 || e == 64 || e == 128; }
 

@@ -95,6 +95,28 @@ int nnop_llama_rope(const nnop_rope_desc* d, void* q_out, void* k_out, const voi
     return launch_rope(*d, q_out, k_out, q, k, cos, sin, sin_sign, (hipStream_t)stream);
 }
 
+static int check_softmax(const nnop_softmax_desc* d) {
+    if (!d) return NNOP_ERR_NULL;
+    if (d->dtype != NNOP_F32 && d->dtype != NNOP_F16 && d->dtype != NNOP_BF16) return NNOP_ERR_DTYPE;
+    if (d->n <= 0 || d->batch <= 0) return NNOP_ERR_SHAPE;
+    return NNOP_OK;
+}
+
+int nnop_online_softmax(const nnop_softmax_desc* d, void* y, const void* x, nnop_stream_t stream) {
+    const int st = check_softmax(d);
+    if (st != NNOP_OK) return st;
+    if (!y || !x) return NNOP_ERR_NULL;
+    return launch_softmax(*d, y, x, nullptr, false, (hipStream_t)stream);
+}
+
+int nnop_online_softmax_bwd(const nnop_softmax_desc* d, void* dx, const void* dy, const void* y,
+                            nnop_stream_t stream) {
+    const int st = check_softmax(d);
+    if (st != NNOP_OK) return st;
+    if (!dx || !dy || !y) return NNOP_ERR_NULL;
+    return launch_softmax(*d, dx, dy, y, true, (hipStream_t)stream);
+}
+
 size_t nnop_fa_bwd_workspace_bytes(const nnop_fa_desc* d) {
     if (check_desc(d) != NNOP_OK) return 0;
     return bwd_workspace_bytes(*d);

@@ -9,6 +9,7 @@
 #   NNop._flash_attention(q,k,v,pair; causal,kpad_mask)       src/attention.jl:133-177   -> (o, ms, ls)
 #   NNop.∇flash_attention(Δ,o,ms,ls,q,k,v,pair; causal,...)   src/attention_bwd.jl:199-275 -> (dq,dk,dv,dpair)
 #   NNop._llama_rope(q, k, cos, sin; bwd)                     src/rope/llama_rope.jl:69-89 -> (q', k')
+#   NNop.online_softmax(x) / NNop.∇online_softmax(Δ, y)       src/softmax.jl:60-80
 #
 # `flash_attention` and the ChainRules `rrule` (src/attention_crc.jl:4-31) call these generically, so
 # `NNop.flash_attention(q, k, v; causal)` and `Zygote.gradient` keep working unchanged.
@@ -133,6 +134,33 @@ function NNop._llama_rope(
         d, devptr(qo), devptr(ko), devptr(q), devptr(k), devptr(cos), devptr(sin), bwd ? -1f0 : 1f0, hipstream())
     st == 0 || error("libnnop_hip: " * unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st)))
     return qo, ko
+end
+
+# struct nnop_softmax_desc (include/nnop_hip.h)
+struct SoftmaxDesc
+    dtype::Int32; n::Int32; batch::Int64
+end
+
+# src/softmax.jl:60-68.  The rrule (:82-86) calls online_softmax / ∇online_softmax generically.
+function NNop.online_softmax(x::ROCMatrix{T}) where T <: HipFloat
+    y = similar(x)
+    d = Ref(SoftmaxDesc(nnop_dtype(T), size(x, 1), size(x, 2)))
+    st = ccall((:nnop_online_softmax, libnnop()), Cint, (Ptr{SoftmaxDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        d, devptr(y), devptr(x), hipstream())
+    st == 0 || error("libnnop_hip: " * unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st)))
+    return y
+end
+
+# src/softmax.jl:70-80: the two broadcasts + reduction fused into one pass (first derivatives only, like the
+# reference's fast path :75-78; under nested differentiation the generic method still applies).
+function NNop.∇online_softmax(Δ::ROCMatrix{T}, y::ROCMatrix{T}) where T <: HipFloat
+    NNop.within_gradient(y) && return invoke(NNop.∇online_softmax, Tuple{AbstractArray, AbstractArray}, Δ, y)
+    dx = similar(y)
+    d = Ref(SoftmaxDesc(nnop_dtype(T), size(y, 1), size(y, 2)))
+    st = ccall((:nnop_online_softmax_bwd, libnnop()), Cint,
+        (Ptr{SoftmaxDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), d, devptr(dx), devptr(Δ), devptr(y), hipstream())
+    st == 0 || error("libnnop_hip: " * unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st)))
+    return dx
 end
 
 end # module

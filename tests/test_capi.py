@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_header_compiles_as_plain_c(tmp_path):
     c = tmp_path / "t.c"
-    c.write_text('#include "nnop_hip.h"\nint main(void){ nnop_fa_desc d; (void)d; return NNOP_HIP_ABI_VERSION - 2; }\n')
+    c.write_text('#include "nnop_hip.h"\nint main(void){ nnop_fa_desc d; (void)d; return NNOP_HIP_ABI_VERSION > 0 ? 0 : 1; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c),
                     "-o", str(tmp_path / "t")], check=True)
     assert subprocess.run([str(tmp_path / "t")]).returncode == 0
@@ -42,7 +42,8 @@ def test_header_compiles_as_plain_c(tmp_path):
 
 def test_abi_version_and_strerror(pkg):
     lib = pkg._lib.load()
-    assert lib.nnop_abi_version() == 2
+    assert lib.nnop_abi_version() == pkg._lib.ABI_VERSION
+    assert int(re.search(r"#define NNOP_HIP_ABI_VERSION (\d+)", open(HEADER).read()).group(1)) == pkg._lib.ABI_VERSION
     assert pkg._lib.strerror(0) == "success"
     assert "power-of-2" in pkg._lib.strerror(pkg._lib.NNOP_ERR_EMB_NOT_POW2)
     assert "divisible" in pkg._lib.strerror(pkg._lib.NNOP_ERR_HEADS)
