@@ -170,6 +170,40 @@ int nnop_online_softmax(const nnop_softmax_desc* d, void* y, const void* x, nnop
 int nnop_online_softmax_bwd(const nnop_softmax_desc* d, void* dx, const void* dy, const void* y,
                             nnop_stream_t stream);
 
+/*
+ * RMSNorm and LayerNorm.
+ *   NNop._rms_norm(x, w; ϵ, offset) -> (y, rms)                  src/rms_norm.jl:117-137 (kernel :3-38)
+ *   NNop.∇rms_norm(Δ, rms, x, w; offset) -> (dx, dw)              src/rms_norm.jl:139-169 (kernel :43-115)
+ *   NNop._layer_norm(x, w, b; ϵ) -> (y, μ, Σ)                     src/layer_norm.jl:150-170 (kernel :8-63)
+ *   NNop.∇layer_norm(Δ, μ, Σ, x, w, b) -> (dx, dw, db)            src/layer_norm.jl:172-204 (kernel :65-148)
+ * x, y, dy, dx : [n][emb] == Julia (emb, n), element type `dtype`;  w, b : [emb], element type `w_dtype`
+ * (NNOP_F32 or the same as dtype);  rms, mu, sigma : fp32 [n] (the caches the reference keeps for the pullback:
+ * rms = sigma = 1/sqrt(var + eps));  RMSNorm dw : fp32 [emb] (rms_norm.jl:146);  LayerNorm dw, db : `w_dtype` [emb]
+ * (layer_norm.jl:179-180).  Any emb >= 1.  fp32 arithmetic, one rounding on store.
+ * The pullbacks need caller-owned scratch of nnop_norm_bwd_workspace_bytes() (replaces the reference's
+ * (n/4, emb) partial-sum arrays, rms_norm.jl:146, layer_norm.jl:179-180); dx, dw, db are fully overwritten.
+ */
+typedef struct nnop_norm_desc {
+    int32_t dtype;     /* nnop_dtype of x, y, dy, dx */
+    int32_t w_dtype;   /* nnop_dtype of w, b (and of LayerNorm's dw, db) */
+    int32_t emb;       /* size(x,1) */
+    int32_t reserved;  /* must be 0 */
+    int64_t n;         /* size(x,2) */
+} nnop_norm_desc;
+
+int nnop_rms_norm(const nnop_norm_desc* d, void* y, float* rms, const void* x, const void* w,
+                  float offset, float eps, nnop_stream_t stream);
+int nnop_rms_norm_bwd(const nnop_norm_desc* d, void* dx, float* dw, const void* dy, const float* rms,
+                      const void* x, const void* w, float offset,
+                      void* workspace, size_t workspace_bytes, nnop_stream_t stream);
+int nnop_layer_norm(const nnop_norm_desc* d, void* y, float* mu, float* sigma, const void* x, const void* w,
+                    const void* b, float eps, nnop_stream_t stream);
+int nnop_layer_norm_bwd(const nnop_norm_desc* d, void* dx, void* dw, void* db, const void* dy, const float* mu,
+                        const float* sigma, const void* x, const void* w,
+                        void* workspace, size_t workspace_bytes, nnop_stream_t stream);
+/* layer_norm: 0 = RMSNorm pullback, 1 = LayerNorm pullback.  Returns 0 for an invalid descriptor. */
+size_t nnop_norm_bwd_workspace_bytes(const nnop_norm_desc* d, int layer_norm);
+
 /* NNop._shared_memory(::ROCBackend, device_id) (ext/NNopAMDGPUExt.jl:6-9):
  * hipDeviceProp_t.sharedMemPerBlock of `device` (0-based HIP ordinal). */
 int nnop_shared_memory(int device, uint64_t* bytes);
@@ -178,7 +212,7 @@ int nnop_shared_memory(int device, uint64_t* bytes);
 const char* nnop_strerror(int status);
 
 /* ABI version of this header: bumped on any incompatible change. */
-#define NNOP_HIP_ABI_VERSION 3
+#define NNOP_HIP_ABI_VERSION 4
 int nnop_abi_version(void);
 
 #ifdef __cplusplus

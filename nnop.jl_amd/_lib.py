@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NNOP_LIB_PATH") or os.path.join(_HERE, "lib", "libnnop_hip.so")
 
 # NNOP_HIP_ABI_VERSION of the header this binding was written against; load() refuses another library
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # nnop_dtype (include/nnop_hip.h)
 NNOP_F32, NNOP_F16, NNOP_BF16 = 0, 1, 2
@@ -39,6 +39,11 @@ EXPORTED_SYMBOLS = (
     "nnop_llama_rope",
     "nnop_online_softmax",
     "nnop_online_softmax_bwd",
+    "nnop_rms_norm",
+    "nnop_rms_norm_bwd",
+    "nnop_layer_norm",
+    "nnop_layer_norm_bwd",
+    "nnop_norm_bwd_workspace_bytes",
     "nnop_shared_memory",
     "nnop_strerror",
     "nnop_abi_version",
@@ -65,6 +70,12 @@ class RopeDesc(C.Structure):
 class SoftmaxDesc(C.Structure):
     """struct nnop_softmax_desc"""
     _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("batch", C.c_int64)]
+
+
+class NormDesc(C.Structure):
+    """struct nnop_norm_desc"""
+    _fields_ = [("dtype", C.c_int32), ("w_dtype", C.c_int32), ("emb", C.c_int32), ("reserved", C.c_int32),
+                ("n", C.c_int64)]
 
 
 class NNopLibraryMissing(ImportError):
@@ -98,6 +109,17 @@ def load():
     lib.nnop_online_softmax.argtypes = [C.POINTER(SoftmaxDesc), vp, vp, vp]
     lib.nnop_online_softmax_bwd.restype = C.c_int
     lib.nnop_online_softmax_bwd.argtypes = [C.POINTER(SoftmaxDesc), vp, vp, vp, vp]
+    nd = C.POINTER(NormDesc)
+    lib.nnop_rms_norm.restype = C.c_int
+    lib.nnop_rms_norm.argtypes = [nd, vp, vp, vp, vp, C.c_float, C.c_float, vp]
+    lib.nnop_rms_norm_bwd.restype = C.c_int
+    lib.nnop_rms_norm_bwd.argtypes = [nd, vp, vp, vp, vp, vp, vp, C.c_float, vp, C.c_size_t, vp]
+    lib.nnop_layer_norm.restype = C.c_int
+    lib.nnop_layer_norm.argtypes = [nd, vp, vp, vp, vp, vp, vp, C.c_float, vp]
+    lib.nnop_layer_norm_bwd.restype = C.c_int
+    lib.nnop_layer_norm_bwd.argtypes = [nd, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.nnop_norm_bwd_workspace_bytes.restype = C.c_size_t
+    lib.nnop_norm_bwd_workspace_bytes.argtypes = [nd, C.c_int]
     lib.nnop_shared_memory.restype = C.c_int
     lib.nnop_shared_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.nnop_strerror.restype = C.c_char_p

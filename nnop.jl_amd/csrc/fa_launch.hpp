@@ -32,6 +32,17 @@ int launch_rope(const nnop_rope_desc& d, void* qo, void* ko, const void* q, cons
 // softmax.hip (a = x | dy, b = nullptr | y)
 int launch_softmax(const nnop_softmax_desc& d, void* out, const void* a, const void* b, bool bwd, hipStream_t s);
 
+// rms_norm.hip / layer_norm.hip (ws: caller scratch of norm_ws_bytes)
+int launch_rms_norm(const nnop_norm_desc& d, void* y, float* rms, const void* x, const void* w, float offset, float eps,
+                    hipStream_t s);
+int launch_rms_norm_bwd(const nnop_norm_desc& d, void* dx, float* dw, const void* dy, const float* rms, const void* x,
+                        const void* w, float offset, void* ws, hipStream_t s);
+int launch_layer_norm(const nnop_norm_desc& d, void* y, float* mu, float* sigma, const void* x, const void* w,
+                      const void* b, float eps, hipStream_t s);
+int launch_layer_norm_bwd(const nnop_norm_desc& d, void* dx, void* dw, void* db, const void* dy, const float* mu,
+                          const float* sigma, const void* x, const void* w, void* ws, hipStream_t s);
+size_t norm_ws_bytes(const nnop_norm_desc& d, bool ln);
+
 // Embedding dims the MFMA kernels are instantiated for.
 inline bool emb_supported(int e) { return e == 16 || e == 32 || e == 64 || e == 128; }
 

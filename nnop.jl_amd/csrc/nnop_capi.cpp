@@ -52,7 +52,7 @@ const char* nnop_strerror(int status) {
         case NNOP_ERR_EMB_UNSUPPORTED:
             return "Failed to find a Flash Attention tile configuration for this embedding dim (supported: 16, 32, 64, 128).";
         case NNOP_ERR_SHAPE: return "A dimension is non-positive or too large.";
-        case NNOP_ERR_WORKSPACE: return "Backward workspace is smaller than nnop_fa_bwd_workspace_bytes().";
+        case NNOP_ERR_WORKSPACE: return "Backward workspace is smaller than nnop_*_bwd_workspace_bytes().";
         case NNOP_ERR_HIP: return "HIP runtime error at kernel launch.";
         default: return "unknown nnop status";
     }
@@ -115,6 +115,54 @@ int nnop_online_softmax_bwd(const nnop_softmax_desc* d, void* dx, const void* dy
     if (st != NNOP_OK) return st;
     if (!dx || !dy || !y) return NNOP_ERR_NULL;
     return launch_softmax(*d, dx, dy, y, true, (hipStream_t)stream);
+}
+
+static int check_norm(const nnop_norm_desc* d) {
+    if (!d) return NNOP_ERR_NULL;
+    if (d->dtype != NNOP_F32 && d->dtype != NNOP_F16 && d->dtype != NNOP_BF16) return NNOP_ERR_DTYPE;
+    if (d->w_dtype != NNOP_F32 && d->w_dtype != d->dtype) return NNOP_ERR_DTYPE;
+    if (d->emb <= 0 || d->n <= 0 || d->n > 0x7fffffffLL || d->reserved != 0) return NNOP_ERR_SHAPE;
+    return NNOP_OK;
+}
+
+int nnop_rms_norm(const nnop_norm_desc* d, void* y, float* rms, const void* x, const void* w, float offset, float eps,
+                  nnop_stream_t stream) {
+    const int st = check_norm(d);
+    if (st != NNOP_OK) return st;
+    if (!y || !rms || !x || !w) return NNOP_ERR_NULL;
+    return launch_rms_norm(*d, y, rms, x, w, offset, eps, (hipStream_t)stream);
+}
+
+int nnop_rms_norm_bwd(const nnop_norm_desc* d, void* dx, float* dw, const void* dy, const float* rms, const void* x,
+                      const void* w, float offset, void* workspace, size_t workspace_bytes, nnop_stream_t stream) {
+    const int st = check_norm(d);
+    if (st != NNOP_OK) return st;
+    if (!dx || !dw || !dy || !rms || !x || !w || !workspace) return NNOP_ERR_NULL;
+    if (workspace_bytes < norm_ws_bytes(*d, false)) return NNOP_ERR_WORKSPACE;
+    return launch_rms_norm_bwd(*d, dx, dw, dy, rms, x, w, offset, workspace, (hipStream_t)stream);
+}
+
+int nnop_layer_norm(const nnop_norm_desc* d, void* y, float* mu, float* sigma, const void* x, const void* w,
+                    const void* b, float eps, nnop_stream_t stream) {
+    const int st = check_norm(d);
+    if (st != NNOP_OK) return st;
+    if (!y || !mu || !sigma || !x || !w || !b) return NNOP_ERR_NULL;
+    return launch_layer_norm(*d, y, mu, sigma, x, w, b, eps, (hipStream_t)stream);
+}
+
+int nnop_layer_norm_bwd(const nnop_norm_desc* d, void* dx, void* dw, void* db, const void* dy, const float* mu,
+                        const float* sigma, const void* x, const void* w, void* workspace, size_t workspace_bytes,
+                        nnop_stream_t stream) {
+    const int st = check_norm(d);
+    if (st != NNOP_OK) return st;
+    if (!dx || !dw || !db || !dy || !mu || !sigma || !x || !w || !workspace) return NNOP_ERR_NULL;
+    if (workspace_bytes < norm_ws_bytes(*d, true)) return NNOP_ERR_WORKSPACE;
+    return launch_layer_norm_bwd(*d, dx, dw, db, dy, mu, sigma, x, w, workspace, (hipStream_t)stream);
+}
+
+size_t nnop_norm_bwd_workspace_bytes(const nnop_norm_desc* d, int layer_norm) {
+    if (check_norm(d) != NNOP_OK) return 0;
+    return norm_ws_bytes(*d, layer_norm != 0);
 }
 
 size_t nnop_fa_bwd_workspace_bytes(const nnop_fa_desc* d) {

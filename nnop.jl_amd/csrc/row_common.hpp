@@ -138,6 +138,25 @@ template <typename T, int ROWS_HELD, typename F> static inline bool dispatch_row
     return false;
 }
 
+// Shapes for kernels that keep several rows plus per-column fp32 accumulators live (the norm pullbacks): at most 16
+// columns per lane (4 chunks of fp32, 2 of a 16-bit type), wider groups instead.
+template <typename T, typename F> static inline bool dispatch_row_shape_narrow(long long N, F&& f) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr bool F32 = sizeof(T) == 4;
+    if (N % VEC != 0) return false;
+    const long long chunks = N / VEC;
+    if (chunks <= 64 * 1) { f(RowShape<64, 1>{}); return true; }
+    if (chunks <= 64 * 2) { f(RowShape<64, 2>{}); return true; }
+    if constexpr (F32) { if (chunks <= 64 * 4) { f(RowShape<64, 4>{}); return true; } }
+    if (chunks <= 256 * 1) { f(RowShape<256, 1>{}); return true; }
+    if (chunks <= 256 * 2) { f(RowShape<256, 2>{}); return true; }
+    if constexpr (F32) { if (chunks <= 256 * 4) { f(RowShape<256, 4>{}); return true; } }
+    if (chunks <= 1024 * 1) { f(RowShape<1024, 1>{}); return true; }
+    if (chunks <= 1024 * 2) { f(RowShape<1024, 2>{}); return true; }
+    if constexpr (F32) { if (chunks <= 1024 * 4) { f(RowShape<1024, 4>{}); return true; } }
+    return false;
+}
+
 // Opaque fence on a register row: values derived from it before the fence (fp32 expansions of a 16-bit row) cannot be
 // kept alive across it, so a second pass re-converts from the packed registers instead of doubling the footprint.
 template <typename R> NNOP_DEV void repack(R& r) {

@@ -10,6 +10,8 @@
 #   NNop.∇flash_attention(Δ,o,ms,ls,q,k,v,pair; causal,...)   src/attention_bwd.jl:199-275 -> (dq,dk,dv,dpair)
 #   NNop._llama_rope(q, k, cos, sin; bwd)                     src/rope/llama_rope.jl:69-89 -> (q', k')
 #   NNop.online_softmax(x) / NNop.∇online_softmax(Δ, y)       src/softmax.jl:60-80
+#   NNop._rms_norm / NNop.∇rms_norm                           src/rms_norm.jl:117-169
+#   NNop._layer_norm / NNop.∇layer_norm                       src/layer_norm.jl:150-204
 #
 # `flash_attention` and the ChainRules `rrule` (src/attention_crc.jl:4-31) call these generically, so
 # `NNop.flash_attention(q, k, v; causal)` and `Zygote.gradient` keep working unchanged.
@@ -161,6 +163,58 @@ function NNop.∇online_softmax(Δ::ROCMatrix{T}, y::ROCMatrix{T}) where T <: Hi
         (Ptr{SoftmaxDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), d, devptr(dx), devptr(Δ), devptr(y), hipstream())
     st == 0 || error("libnnop_hip: " * unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st)))
     return dx
+end
+
+# struct nnop_norm_desc (include/nnop_hip.h)
+struct NormDesc
+    dtype::Int32; w_dtype::Int32; emb::Int32; reserved::Int32; n::Int64
+end
+normdesc(x, w) = Ref(NormDesc(nnop_dtype(eltype(x)), nnop_dtype(eltype(w)), size(x, 1), 0, size(x, 2)))
+ok(st) = st == 0 || error("libnnop_hip: " * unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st)))
+
+# src/rms_norm.jl:117-137 (the public rms_norm and the rrule, :171-185, call these generically)
+function NNop._rms_norm(x::ROCMatrix{T}, w::ROCVector{W}; ϵ::Float32, offset::Float32 = 0f0) where {T <: HipFloat, W <: HipFloat}
+    @assert size(x, 1) == length(w)
+    y = similar(x); rms = ROCArray{Float32}(undef, size(x, 2))
+    ok(ccall((:nnop_rms_norm, libnnop()), Cint,
+        (Ptr{NormDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Cfloat, Ptr{Cvoid}),
+        normdesc(x, w), devptr(y), devptr(rms), devptr(x), devptr(w), offset, ϵ, hipstream()))
+    return y, rms
+end
+
+# src/rms_norm.jl:139-169: dw comes back already summed over rows (Float32, :146)
+function NNop.∇rms_norm(Δ::ROCMatrix{T}, rms::ROCVector{Float32}, x::ROCMatrix{T}, w::ROCVector{W};
+                        offset::Float32) where {T <: HipFloat, W <: HipFloat}
+    d = normdesc(x, w)
+    dx = similar(x); dw = ROCArray{Float32}(undef, size(x, 1))
+    nbytes = ccall((:nnop_norm_bwd_workspace_bytes, libnnop()), Csize_t, (Ptr{NormDesc}, Cint), d, 0)
+    ws = ROCArray{UInt8}(undef, nbytes)
+    ok(ccall((:nnop_rms_norm_bwd, libnnop()), Cint,
+        (Ptr{NormDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+        d, devptr(dx), devptr(dw), devptr(Δ), devptr(rms), devptr(x), devptr(w), offset, devptr(ws), nbytes, hipstream()))
+    return dx, dw
+end
+
+# src/layer_norm.jl:150-170
+function NNop._layer_norm(x::ROCMatrix{T}, w::ROCVector{W}, b::ROCVector{W}; ϵ::Float32 = 1f-6) where {T <: HipFloat, W <: HipFloat}
+    y = similar(x); μ = ROCArray{Float32}(undef, size(x, 2)); Σ = similar(μ)
+    ok(ccall((:nnop_layer_norm, libnnop()), Cint,
+        (Ptr{NormDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}),
+        normdesc(x, w), devptr(y), devptr(μ), devptr(Σ), devptr(x), devptr(w), devptr(b), ϵ, hipstream()))
+    return y, μ, Σ
+end
+
+# src/layer_norm.jl:172-204: dw, db in eltype(w) (:179-180), already summed over rows
+function NNop.∇layer_norm(Δ::ROCMatrix{T}, μ::ROCVector{Float32}, Σ::ROCVector{Float32}, x::ROCMatrix{T},
+                          w::ROCVector{W}, b::ROCVector{W}) where {T <: HipFloat, W <: HipFloat}
+    d = normdesc(x, w)
+    dx = similar(x); dw = similar(w); db = similar(b)
+    nbytes = ccall((:nnop_norm_bwd_workspace_bytes, libnnop()), Csize_t, (Ptr{NormDesc}, Cint), d, 1)
+    ws = ROCArray{UInt8}(undef, nbytes)
+    ok(ccall((:nnop_layer_norm_bwd, libnnop()), Cint,
+        (Ptr{NormDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+        d, devptr(dx), devptr(dw), devptr(db), devptr(Δ), devptr(μ), devptr(Σ), devptr(x), devptr(w), devptr(ws), nbytes, hipstream()))
+    return dx, dw, db
 end
 
 end # module

@@ -74,3 +74,12 @@ def assert_close(name, got, ref, dt, scale=1.0, floor=False):
         nrm = np.linalg.norm(gz - rz)
         assert nrm <= max(1e-3, 1e-3 * max(np.linalg.norm(gz), np.linalg.norm(rz))), f"{name}: norm-wise 1e-3"
     return float(err.max() / max(mag, 1e-30))
+
+
+def jl_isapprox(got, ref, atol=0.0, rtol=None):
+    """Julia's isapprox for ARRAYS, as the reference's tests use it: norm(x - y) <= max(atol, rtol*max(norm(x), norm(y)))
+    -- a norm-wise criterion (Frobenius), not element-wise; default rtol = sqrt(eps(Float32)) when atol == 0."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    if rtol is None:
+        rtol = float(np.sqrt(np.finfo(np.float32).eps)) if atol == 0.0 else 0.0
+    return np.linalg.norm(got - ref) <= max(atol, rtol * max(np.linalg.norm(got), np.linalg.norm(ref)))

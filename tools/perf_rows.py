@@ -59,6 +59,38 @@ def softmax():
                               kind="port", cores=1, sample="N4096 batch4096 f32, median of 5")), flush=True)
 
 
+def norms():
+    from oracle.naive_norms import norm_bytes
+    for emb, n, dt in [(1024, 1024, "f32"), (4096, 16384, "bf16"), (4096, 16384, "f32"), (8192, 8192, "bf16"),
+                       (768, 65536, "bf16"), (16384, 4096, "bf16"), (5120, 16384, "bf16")]:
+        x = torch.randn(n, emb, device=DEV).to(DT[dt])
+        dy = torch.randn(n, emb, device=DEV).to(DT[dt])
+        w = torch.randn(emb, device=DEV); b = torch.randn(emb, device=DEV)
+        shape = f"emb{emb} n{n}"
+        nb_f, nb_b = norm_bytes(emb, n, x.element_size()), norm_bytes(emb, n, x.element_size(), bwd=True)
+        us = timeit(lambda: pkg._rms_norm(x, w))
+        us_t = timeit(lambda: torch.nn.functional.rms_norm(x, (emb,), w.to(x.dtype)))
+        line("rms_norm", shape, dt, us, nb_f, us_torch=round(us_t, 2))
+        y, rms = pkg._rms_norm(x, w)
+        line("grad_rms_norm", shape, dt, timeit(lambda: pkg.grad_rms_norm(dy, rms, x, w)), nb_b)
+        us = timeit(lambda: pkg._layer_norm(x, w, b))
+        us_t = timeit(lambda: torch.nn.functional.layer_norm(x, (emb,), w.to(x.dtype), b.to(x.dtype)))
+        line("layer_norm", shape, dt, us, nb_f, us_torch=round(us_t, 2))
+        y, mu, sg = pkg._layer_norm(x, w, b)
+        line("grad_layer_norm", shape, dt, timeit(lambda: pkg.grad_layer_norm(dy, mu, sg, x, w, b)), nb_b)
+    if "--cpu" in sys.argv:
+        from oracle.naive_norms import naive_layer_norm, naive_rms_norm
+        xs = np.random.default_rng(0).standard_normal((4096, 4096)).astype(np.float32)
+        ws = np.ones(4096, np.float32)
+        for name, fn in (("rms_norm", lambda: naive_rms_norm(xs, ws, dtype=np.float32)),
+                         ("layer_norm", lambda: naive_layer_norm(xs, ws, ws, dtype=np.float32))):
+            t = []
+            for _ in range(5):
+                t0 = time.perf_counter(); fn(); t.append(time.perf_counter() - t0)
+            print(json.dumps(dict(op=name, cpu_baseline_gbps=round(norm_bytes(4096, 4096, 4) / np.median(t) / 1e9, 2),
+                                  kind="port", cores=1, sample="emb4096 n4096 f32, median of 5")), flush=True)
+
+
 if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["softmax"]
     for w in which:
