@@ -17,6 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle.naive_attention import naive_attention, naive_attention_grads  # noqa: E402
 from oracle.naive_rope import llama_rotary_embedding, naive_llama_rope, pairwise_llama_rope  # noqa: E402
+from oracle.naive_softmax import naive_softmax, naive_softmax_grad  # noqa: E402
+from oracle.naive_norms import (naive_rms_norm, naive_rms_norm_grads, naive_layer_norm,  # noqa: E402
+                                naive_layer_norm_grads)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -87,12 +90,43 @@ def make_rope_case(seed, B, QH, KH, L, D, off):
     return d
 
 
+# Row operators.  name: (seed, n, emb): one matrix serves softmax, RMSNorm and LayerNorm
+ROW_CASES = {
+    "wave_520":     (30, 23, 520),       # wave-per-row register shape, partial last chunk
+    "odd_257":      (31, 17, 257),       # odd length: generic kernels (reference grid value)
+    "block_4096":   (32, 9, 4096),       # workgroup-per-row shape
+}
+
+
+def make_row_case(seed, n, emb):
+    rng = np.random.default_rng(seed)
+    g = lambda *s: bf16_round(rng.standard_normal(s).astype(np.float32))
+    d = dict(x=g(n, emb), dy=g(n, emb), w=g(emb), b=g(emb), offset=np.float32(0.5), eps=np.float32(1e-5))
+    y = naive_softmax(d["x"])
+    d["softmax_y"] = y.astype(np.float32)
+    # the pullback is taken at the fp32-rounded y stored here (what a caller would hand back)
+    d["softmax_dx"] = naive_softmax_grad(d["dy"], d["softmax_y"]).astype(np.float32)
+    yr, rstd = naive_rms_norm(d["x"], d["w"], offset=0.5, eps=1e-5)
+    dxr, dwr = naive_rms_norm_grads(d["dy"], d["x"], d["w"], offset=0.5, eps=1e-5)
+    d.update(rms_y=yr.astype(np.float32), rms_rstd=rstd.astype(np.float32), rms_dx=dxr.astype(np.float32),
+             rms_dw=dwr.astype(np.float32))
+    yl, mu, sg = naive_layer_norm(d["x"], d["w"], d["b"], eps=1e-5)
+    dxl, dwl, dbl = naive_layer_norm_grads(d["dy"], d["x"], d["w"], eps=1e-5)
+    d.update(ln_y=yl.astype(np.float32), ln_mu=mu.astype(np.float32), ln_sigma=sg.astype(np.float32),
+             ln_dx=dxl.astype(np.float32), ln_dw=dwl.astype(np.float32), ln_db=dbl.astype(np.float32))
+    return d
+
+
 def main():
+    for name, cfg in ROW_CASES.items():
+        d = make_row_case(*cfg)
+        np.savez_compressed(os.path.join(HERE, f"rows_{name}.npz"), **d)
+        print("rows", name, d["x"].shape)
     for name, cfg in ROPE_CASES.items():
         d = make_rope_case(*cfg)
         np.savez_compressed(os.path.join(HERE, f"rope_{name}.npz"), **d)
         print("rope", name, {k: v.shape for k, v in d.items()})
-    if "--rope-only" in sys.argv:
+    if "--no-attention" in sys.argv:
         return
     for name, cfg in CASES.items():
         d = make_case(*cfg)

@@ -70,3 +70,9 @@ def test_shard_views_are_views_and_gqa_heads_stay_together(pkg):
     assert qs.shape == (1, 4, 3, 4) and ks.shape == (1, 1, 5, 4)
     assert qs.data_ptr() == q[1, 4].data_ptr() and ks.data_ptr() == k[1, 1].data_ptr()
     assert qs.is_contiguous() and ks.is_contiguous()
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() (what the driver calls every round) compiles, loads and checks the ABI version."""
+    import __graft_entry__ as g
+    g.build()

@@ -94,3 +94,23 @@ def test_norm_host_refuses_cpu_tensors(pkg):
         pkg.rms_norm(x, w)
     with pytest.raises(pkg.NNopError, match="GPU-only"):
         pkg.layer_norm(x, w, w)
+
+
+def test_oracle_reproduces_row_golden_fixtures():
+    """tests/golden/rows_*.npz (make_golden.py) are what the oracles compute today, for softmax and both norms."""
+    import glob
+    import os
+    from oracle.naive_softmax import naive_softmax, naive_softmax_grad
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "rows_*.npz")))
+    assert len(files) >= 3
+    for f in files:
+        g = np.load(f)
+        off, eps = float(g["offset"]), float(g["eps"])
+        np.testing.assert_allclose(naive_softmax(g["x"]), g["softmax_y"], rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(naive_softmax_grad(g["dy"], g["softmax_y"]), g["softmax_dx"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(naive_rms_norm(g["x"], g["w"], offset=off, eps=eps)[0], g["rms_y"], rtol=1e-6, atol=1e-6)
+        dx, dw = naive_rms_norm_grads(g["dy"], g["x"], g["w"], offset=off, eps=eps)
+        np.testing.assert_allclose(dx, g["rms_dx"], rtol=1e-6, atol=1e-6); np.testing.assert_allclose(dw, g["rms_dw"], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(naive_layer_norm(g["x"], g["w"], g["b"], eps=eps)[0], g["ln_y"], rtol=1e-6, atol=1e-6)
+        dx, dw, db = naive_layer_norm_grads(g["dy"], g["x"], g["w"], eps=eps)
+        np.testing.assert_allclose(dx, g["ln_dx"], rtol=1e-6, atol=1e-6); np.testing.assert_allclose(db, g["ln_db"], rtol=1e-6, atol=1e-5)

@@ -191,3 +191,37 @@ def test_host_checks(pkg):
         pkg.layer_norm(x.half(), w.half(), w)           # w, b of different dtypes
     with pytest.raises(TypeError):
         pkg.rms_norm(x[0], w)
+
+
+import glob as _glob
+import os as _os
+
+_ROW_GOLDEN = sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "rows_*.npz")))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("path", _ROW_GOLDEN, ids=[_os.path.basename(p)[5:-4] for p in _ROW_GOLDEN])
+def test_row_golden(pkg, path, dt):
+    """Committed fixtures (bf16-exact inputs, fp64-oracle outputs): softmax, RMSNorm, LayerNorm, forward + pullback."""
+    g = np.load(path)
+    off, eps = float(g["offset"]), float(g["eps"])
+    x, dy = _t(g["x"], dt), _t(g["dy"], dt)
+    w, b = _t(g["w"], "f32"), _t(g["b"], "f32")
+    f64 = lambda n: g[n].astype(np.float64)
+    y = pkg.online_softmax(x)
+    np.testing.assert_allclose(_np(y), f64("softmax_y"), rtol=YTOL[dt]["rtol"] * 1.5, atol=1e-7)
+    if dt == "f32":       # the fixture's pullback is taken at the fp32 y; 16-bit y differs by its own rounding
+        np.testing.assert_allclose(_np(pkg.grad_online_softmax(dy, _t(g["softmax_y"], dt))), f64("softmax_dx"),
+                                   rtol=1e-5, atol=1e-7)
+    yr, rms = pkg._rms_norm(x, w, offset=off, eps=eps)
+    _close(yr, f64("rms_y"), dt, scale=np.abs(f64("rms_y")).max())
+    np.testing.assert_allclose(_np(rms), f64("rms_rstd"), rtol=2e-6)
+    dx, dw = pkg.grad_rms_norm(dy, rms, x, w, offset=off)
+    _close(dx, f64("rms_dx"), dt, scale=np.abs(f64("rms_dx")).max())
+    np.testing.assert_allclose(_np(dw), f64("rms_dw"), rtol=1e-4, atol=1e-5 * np.abs(f64("rms_dw")).max())
+    yl, mu, sg = pkg._layer_norm(x, w, b, eps=eps)
+    _close(yl, f64("ln_y"), dt, scale=np.abs(f64("ln_y")).max())
+    dx, dw, db = pkg.grad_layer_norm(dy, mu, sg, x, w, b)
+    _close(dx, f64("ln_dx"), dt, scale=np.abs(f64("ln_dx")).max(), k=2.0)
+    np.testing.assert_allclose(_np(dw), f64("ln_dw"), rtol=1e-4, atol=1e-5 * np.abs(f64("ln_dw")).max())
+    np.testing.assert_allclose(_np(db), f64("ln_db"), rtol=1e-4, atol=1e-5 * np.abs(f64("ln_db")).max())
