@@ -7,7 +7,7 @@
 // workgroup is chosen, from how many workgroups the problem yields against the chip's 256 CUs.
 #pragma once
 #include "fa_fwd.hpp"
-#include "fa_fwd_split.hpp"
+#include "fa_fwd_split16.hpp"
 #include "fa_launch.hpp"
 #include <math.h>
 
@@ -40,12 +40,15 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
-// split-KV form (fa_fwd_split.hpp): 16 waves per workgroup, plain mode, 16-bit types, E <= 64
-template <typename T, int E>
+// split-KV form (fa_fwd_split.hpp / fa_fwd_split16.hpp): 16 waves per workgroup, plain mode, 16-bit types, E <= 64.
+// M16: the v_mfma_f32_16x16x32 body (E a multiple of 32), else the 32x32x16 body.
+template <typename T, int E, bool M16>
 static int launch_fwd_split(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
-    constexpr int lds = fa_fwd_split_lds_bytes<T, E>();
+    constexpr int lds = M16 ? fa_fwd_split16_lds_bytes<T, (M16 ? E : 32)>() : fa_fwd_split_lds_bytes<T, E>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = fa_fwd_split_kernel<T, E>;
+    void (*kern)(const FwdParams);
+    if constexpr (M16) kern = fa_fwd_split16_kernel<T, E>;
+    else kern = fa_fwd_split_kernel<T, E>;
     static unsigned long long lds_done = 0;
     if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
     FwdParams p;
@@ -80,7 +83,16 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     if constexpr (sizeof(T) == 2 && E <= 64) {
         // default for plain mode: 16-wave split-KV workgroups (4 waves per SIMD); measured 5-13 % faster than
         // the 8-wave form from 64 to 4096 workgroups.  NNOP_FWD_SPLIT=0 disables.
-        if (mode == 0 && d.ql > 128 && d.kl >= 128 && env_int("NNOP_FWD_SPLIT", 1)) return launch_fwd_split<T, E>(d, a, s);
+        // NNOP_FWD_SPLIT: 0 off; 1 (default) the 32x32x16 body; 16 the v_mfma_16x16x32 body (fa_fwd_split16.hpp) --
+        // correct and tested, measured 7 % SLOWER at C2 (twice the MFMA issues, two extra cross-lane steps per row max;
+        // this kernel is issue-bound, not MFMA-clock-bound -- DESIGN.md section 5), so opt-in only.
+        const int split = env_int("NNOP_FWD_SPLIT", 1);
+        if (mode == 0 && d.ql > 128 && d.kl >= 128 && split) {
+            if constexpr (E % 32 == 0) {
+                if (split == 16) return launch_fwd_split<T, E, true>(d, a, s);
+            }
+            return launch_fwd_split<T, E, false>(d, a, s);
+        }
     }
     int nw = 8, qb = 1;
     if (wg256 < 256 || d.ql <= 128) nw = 4;
