@@ -17,6 +17,10 @@
 #pragma once
 #include "fa_fwd.hpp"
 
+#ifndef NNOP_SPLIT_MFMASUM
+#define NNOP_SPLIT_MFMASUM 0
+#endif
+
 namespace nnop {
 
 template <typename T, int E> constexpr int fa_fwd_split_lds_bytes() {
@@ -99,6 +103,11 @@ __global__ __launch_bounds__(1024) void fa_fwd_split_kernel(const FwdParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[eb][i] = 0.f;
     float m2 = -INFINITY, mt = -INFINITY, lsum = 0.f;      // reference max (log2 units), true max, row sum
+#if NNOP_SPLIT_MFMASUM
+    frag_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = from_f32<T>(1.0f);
+#endif
     const int vbase = VImg::lane_base(lane);
 
     stage_load(0);
@@ -141,8 +150,32 @@ __global__ __launch_bounds__(1024) void fa_fwd_split_kernel(const FwdParams p) {
                 lsum *= alpha;
                 m2 = mn;
             }
-            float lp[4] = {0.f, 0.f, 0.f, 0.f};
             const char* vb = vimg + vbase;
+#if NNOP_SPLIT_MFMASUM
+            // Row sums on the matrix pipe (which has slack at E <= 64; the vector-issue port does not, DESIGN.md
+            // section 5): ones(32 x 16) x P(16 keys x 32 queries) leaves sum_k P[k][query] in every register of the
+            // result; the result tile lives only within this kv tile (in the registers of the consumed score tile),
+            // one v_add per tile folds it into the running sum.  Sums the bf16/fp16-ROUNDED P, i.e. exactly the
+            // weights the PV product uses.
+            f32x16 lt;
+#pragma unroll
+            for (int kk = 0; kk < 2 * KB; ++kk) {
+                const int kb = kk >> 1, i0 = 8 * (kk & 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[kb][i0 + j] = fast_exp2(__builtin_fmaf(s[kb][i0 + j], c2, -m2));
+                const frag_t pf = (kk & 1) ? acc_frag<T, 1>(s[kb]) : acc_frag<T, 0>(s[kb]);
+                if (kk == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) lt[i] = 0.f;
+                }
+                lt = mma16<T>(ones, pf, lt);
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb)
+                    oacc[eb] = mma16<T>(VImg::read_col_frag(vb, kk, eb), pf, oacc[eb]);
+            }
+            lsum += lt[0];
+#else
+            float lp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 2 * KB; ++kk) {
                 const int kb = kk >> 1, i0 = 8 * (kk & 1);
@@ -157,6 +190,7 @@ __global__ __launch_bounds__(1024) void fa_fwd_split_kernel(const FwdParams p) {
                     oacc[eb] = mma16<T>(VImg::read_col_frag(vb, kk, eb), pf, oacc[eb]);
             }
             lsum += (lp[0] + lp[1]) + (lp[2] + lp[3]);
+#endif
         }
         if (more) stage_write((step + 1) & 1);
         __syncthreads();
@@ -181,7 +215,11 @@ __global__ __launch_bounds__(1024) void fa_fwd_split_kernel(const FwdParams p) {
         const float fa = (m2 == -INFINITY) ? 0.f : fast_exp2(m2 - mn);
         const float fb = (m2b == -INFINITY) ? 0.f : fast_exp2(m2b - mn);
         const float mtt = fmaxf(mt, mtb);
+#if NNOP_SPLIT_MFMASUM
+        const float ltot = lsum * fa + lb * fb;            // the MFMA sums already span both lane halves' keys
+#else
         const float ltot = half_swap_sum(lsum * fa + lb * fb);
+#endif
         const float inv = 1.0f / ltot;
         if (qi < p.QL) {
             T* orow = (T*)p.o + ((size_t)bh * p.QL + qi) * E;
