@@ -182,3 +182,46 @@ def test_split_kv_16x16x32_body_matches_oracle(pkg, dev, dt, E, QL, KL, QH, KH, 
         assert_close("ms", res[1], ms_ref, dt)
         lse = res[1].double().cpu().numpy() + np.log(res[2].double().cpu().numpy())
         assert_close("lse", lse, ms_ref + np.log(ls_ref), dt)
+
+
+def test_hip_graph_capture_and_replay(pkg, dev):
+    """The C ABI never allocates, synchronises or touches the default stream, so a forward + backward (and the row
+    operators) capture into a HIP graph; replaying the graph on new data in the static buffers reproduces the eager
+    results bitwise.  This is the launch path for launch-bound shapes (a graph replay costs one submission)."""
+    dt = torch.bfloat16
+    B, QH, KH, L, E = 2, 4, 2, 384, 64
+    g = torch.Generator(device=dev).manual_seed(7)
+    mk = lambda *s: torch.randn(*s, device=dev, generator=g).to(dt)
+    q, k, v, do = mk(B, QH, L, E), mk(B, KH, L, E), mk(B, KH, L, E), mk(B, QH, L, E)
+    o = torch.empty_like(q); ms = torch.empty(B, QH, L, dtype=dt, device=dev); ls = torch.empty_like(ms)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ws = torch.empty(pkg.bwd_workspace_bytes(q, k, v, causal=True), dtype=torch.uint8, device=dev)
+    x = mk(64, 1024); y = torch.empty_like(x); w = torch.ones(1024, device=dev)
+
+    def step():
+        pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=True)
+        pkg.fa_bwd_into(dq, dk, dv, None, ws, do, o, ms, ls, q, k, v, causal=True)
+        pkg.online_softmax_into(y, x)
+
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        step()                                            # warm-up outside capture (sets kernel attributes)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    results = []
+    for seed in (1, 2):
+        g2 = torch.Generator(device=dev).manual_seed(seed)
+        for t in (q, k, v, do, x):
+            t.copy_(torch.randn(t.shape, device=dev, generator=g2).to(dt))
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = [t.clone() for t in (o, ms, ls, dq, dk, dv, y)]
+        step()
+        torch.cuda.synchronize()
+        for a, b_ in zip(replayed, (o, ms, ls, dq, dk, dv, y)):
+            assert torch.equal(a, b_)
+        results.append(replayed[0])
+    assert not torch.equal(results[0], results[1])       # the replays really consumed the new data
