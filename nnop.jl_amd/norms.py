@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import NormDesc
-from .attention import NNopError, _DTYPES, _ptr, _stream
+from .attention import NNopError, _DTYPES, _on_device, _ptr, _stream
 
 __all__ = ["rms_norm", "_rms_norm", "grad_rms_norm", "layer_norm", "_layer_norm", "grad_layer_norm"]
 
@@ -66,7 +66,7 @@ def _rms_norm(x, w, *, eps: float = 1e-6, offset: float = 0.0):
     x, w = x.contiguous(), w.contiguous()
     y = torch.empty_like(x)
     rms = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x):
         _raise(_lib.load().nnop_rms_norm(C.byref(_desc(x, w)), _ptr(y), _ptr(rms), _ptr(x), _ptr(w),
                                          C.c_float(offset), C.c_float(eps), _stream(x)))
     return y, rms
@@ -84,7 +84,7 @@ def grad_rms_norm(dy, rms, x, w, *, offset: float = 0.0):
     dx = torch.empty_like(x)
     dw = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
     ws, nbytes = _workspace(d, False, x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x):
         _raise(_lib.load().nnop_rms_norm_bwd(C.byref(d), _ptr(dx), _ptr(dw), _ptr(dy), _ptr(rms), _ptr(x), _ptr(w),
                                              C.c_float(offset), _ptr(ws), C.c_size_t(nbytes), _stream(x)))
     return dx, dw
@@ -97,7 +97,7 @@ def _layer_norm(x, w, b, *, eps: float = 1e-6):
     y = torch.empty_like(x)
     mu = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
     sigma = torch.empty_like(mu)
-    with torch.cuda.device(x.device):
+    with _on_device(x):
         _raise(_lib.load().nnop_layer_norm(C.byref(_desc(x, w)), _ptr(y), _ptr(mu), _ptr(sigma), _ptr(x), _ptr(w),
                                            _ptr(b), C.c_float(eps), _stream(x)))
     return y, mu, sigma
@@ -116,7 +116,7 @@ def grad_layer_norm(dy, mu, sigma, x, w, b=None):
     dx = torch.empty_like(x)
     dw, db = torch.empty_like(w), torch.empty_like(w)
     ws, nbytes = _workspace(d, True, x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x):
         _raise(_lib.load().nnop_layer_norm_bwd(C.byref(d), _ptr(dx), _ptr(dw), _ptr(db), _ptr(dy), _ptr(mu), _ptr(sigma),
                                                _ptr(x), _ptr(w), _ptr(ws), C.c_size_t(nbytes), _stream(x)))
     return dx, dw, db

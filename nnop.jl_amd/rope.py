@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import RopeDesc
-from .attention import NNopError, _DTYPES, _ptr, _stream
+from .attention import NNopError, _DTYPES, _on_device, _ptr, _stream
 
 __all__ = ["LlamaRotaryEmbedding", "llama_rope", "_llama_rope", "grad_llama_rope", "llama_rope_into"]
 
@@ -80,7 +80,7 @@ def llama_rope_into(q_out, k_out, q, k, cos, sin, *, bwd: bool = False):
             raise NNopError("output buffers must be dense and match q / k in shape, dtype and device")
     B, QH, L, D = q.shape
     d = RopeDesc(dtype=_DTYPES[q.dtype], cs_dtype=_DTYPES[cos.dtype], dim=D, seq=L, qh=QH, kh=k.shape[1], batch=B)
-    with torch.cuda.device(q.device):
+    with _on_device(q):
         st = _lib.load().nnop_llama_rope(C.byref(d), _ptr(q_out), _ptr(k_out), _ptr(q), _ptr(k), _ptr(cos), _ptr(sin),
                                          C.c_float(-1.0 if bwd else 1.0), _stream(q))
     if st != _lib.NNOP_OK:

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import SoftmaxDesc
-from .attention import NNopError, _DTYPES, _ptr, _stream
+from .attention import NNopError, _DTYPES, _on_device, _ptr, _stream
 
 __all__ = ["online_softmax", "grad_online_softmax", "online_softmax_into"]
 
@@ -41,7 +41,7 @@ def online_softmax_into(y, x):
     x = x if x.is_contiguous() else x.contiguous()
     if y.shape != x.shape or y.dtype != x.dtype or y.device != x.device or not y.is_contiguous():
         raise NNopError("output buffer must be dense and match x in shape, dtype and device")
-    with torch.cuda.device(x.device):
+    with _on_device(x):
         st = _lib.load().nnop_online_softmax(C.byref(_desc(x)), _ptr(y), _ptr(x), _stream(x))
     if st != _lib.NNOP_OK:
         raise NNopError(_lib.strerror(st), st)
@@ -55,7 +55,7 @@ def grad_online_softmax(dy, y):
         raise TypeError("Δ must match y in shape, dtype and device")
     dy, y = dy.contiguous(), y.contiguous()
     dx = torch.empty_like(y)
-    with torch.cuda.device(y.device):
+    with _on_device(y):
         st = _lib.load().nnop_online_softmax_bwd(C.byref(_desc(y)), _ptr(dx), _ptr(dy), _ptr(y), _stream(y))
     if st != _lib.NNOP_OK:
         raise NNopError(_lib.strerror(st), st)
