@@ -105,8 +105,8 @@ def main():
     args = parse()
     import torch
     import __graft_entry__ as ge
-    from oracle.naive_attention import attention_flops, attention_bytes      # work model only
     pkg = ge.load_package()
+    attention_flops, attention_bytes = pkg.workmodel.attention_flops, pkg.workmodel.attention_bytes
     pkg._lib.load()                                     # fail loudly if the HIP library is missing
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -14,11 +14,11 @@ from .attention import (NNopError, flash_attention, _flash_attention, grad_flash
 from .rope import LlamaRotaryEmbedding, llama_rope, _llama_rope, grad_llama_rope, llama_rope_into
 from .softmax import online_softmax, grad_online_softmax, online_softmax_into
 from .norms import rms_norm, _rms_norm, grad_rms_norm, layer_norm, _layer_norm, grad_layer_norm
-from . import _lib, shard
+from . import _lib, shard, workmodel
 
 __all__ = ["NNopError", "flash_attention", "_flash_attention", "grad_flash_attention",
            "shared_memory", "bwd_workspace_bytes", "fa_fwd_into", "fa_bwd_into", "LlamaRotaryEmbedding", "llama_rope", "_llama_rope", "grad_llama_rope", "llama_rope_into",
            "online_softmax", "grad_online_softmax", "online_softmax_into",
            "rms_norm", "_rms_norm", "grad_rms_norm", "layer_norm", "_layer_norm", "grad_layer_norm",
-           "shard", "_lib"]
+           "shard", "workmodel", "_lib"]
 __version__ = "0.1.0"

@@ -76,3 +76,25 @@ def test_graft_entry_build_runs():
     """__graft_entry__.build() (what the driver calls every round) compiles, loads and checks the ABI version."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_workmodel_matches_the_oracles_work_model(pkg):
+    """bench.py and the perf tools take FLOPs / bytes from the product's workmodel; the oracles carry the same
+    formulas for the tests -- they must agree."""
+    from oracle.naive_attention import attention_bytes, attention_flops
+    from oracle.naive_norms import norm_bytes
+    from oracle.naive_rope import rope_bytes
+    from oracle.naive_softmax import softmax_bytes
+    wm = pkg.workmodel
+    for causal in (False, True):
+        for mode in ("fwd", "bwd", "fwd+bwd"):
+            assert wm.attention_flops(64, 4096, 4096, 4, 4, causal=causal, mode=mode) == \
+                attention_flops(64, 4096, 4096, 4, 4, causal=causal, mode=mode)
+            assert wm.attention_bytes(128, 300, 500, 8, 2, 3, 2, mode=mode) == attention_bytes(128, 300, 500, 8, 2, 3, 2, mode=mode)
+    assert wm.attention_flops(128, 4096, 4096, 32, 3, causal=False, kv_lens=[100, 4096, 7]) == \
+        attention_flops(128, 4096, 4096, 32, 3, causal=False, kv_lens=[100, 4096, 7])
+    assert wm.attention_flops(64, 4096, 4096, 4, 4, causal=False) == 4 * 64 * 4096 * 4096 * 16
+    assert wm.rope_bytes(128, 4096, 32, 8, 2, 2) == rope_bytes(128, 4096, 32, 8, 2, 2)
+    for bwd in (False, True):
+        assert wm.softmax_bytes(1024, 7, 4, bwd=bwd) == softmax_bytes(1024, 7, 4, bwd=bwd)
+        assert wm.norm_bytes(1024, 7, 2, bwd=bwd) == norm_bytes(1024, 7, 2, bwd=bwd)

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 pkg = g.load_package()
-from oracle.naive_rope import rope_bytes, pairwise_llama_rope  # noqa: E402
+rope_bytes = pkg.workmodel.rope_bytes
 
 HBM_PEAK = 8000.0   # GB/s, MI355X_MICROARCH.md
 DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
@@ -58,6 +58,7 @@ if __name__ == "__main__":
     for s in SHAPES:
         print(json.dumps(run(*s)), flush=True)
     if "--cpu" in sys.argv:
+        from oracle.naive_rope import pairwise_llama_rope      # CPU baseline leg only
         D, L, QH, KH, B = 128, 4096, 32, 8, 1
         rng = np.random.default_rng(0)
         q = rng.standard_normal((B, QH, L, D)).astype(np.float32)

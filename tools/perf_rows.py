@@ -38,7 +38,7 @@ def line(op, shape, dt, us, nbytes, **kw):
 
 
 def softmax():
-    from oracle.naive_softmax import softmax_bytes
+    softmax_bytes = pkg.workmodel.softmax_bytes
     for N, batch, dt in [(1024, 1024, "f32"), (4096, 16384, "f32"), (4096, 16384, "bf16"), (512, 262144, "bf16"),
                          (16384, 8192, "bf16"), (32768, 4096, "bf16"), (131072, 1024, "f32"), (4100, 16384, "f32")]:
         x = torch.randn(batch, N, device=DEV).to(DT[dt])
@@ -60,7 +60,7 @@ def softmax():
 
 
 def norms():
-    from oracle.naive_norms import norm_bytes
+    norm_bytes = pkg.workmodel.norm_bytes
     for emb, n, dt in [(1024, 1024, "f32"), (4096, 16384, "bf16"), (4096, 16384, "f32"), (8192, 8192, "bf16"),
                        (768, 65536, "bf16"), (16384, 4096, "bf16"), (5120, 16384, "bf16")]:
         x = torch.randn(n, emb, device=DEV).to(DT[dt])
