@@ -107,3 +107,85 @@ def test_gradient_linearity_in_cotangent_full_size(pkg, dev):
     g1, g2, g3 = g(d1), g(d2), g((d1.float() - d2.float() * 0.5).to(dt))
     for a, b, c, name in zip(g1, g2, g3, ("dq", "dk", "dv")):
         assert relmax(c, a.float() - 0.5 * b.float()) < 3e-2, name
+
+
+def _fill_normal(t, seed):
+    """N(0,1) into a tensor of more than 2^31 elements, one leading-dim slice at a time (bounded scratch)."""
+    g = torch.Generator(device=t.device).manual_seed(seed)
+    for i in range(t.shape[0]):
+        t[i].copy_(torch.randn(t[i].shape, generator=g, device=t.device, dtype=torch.float32))
+
+
+def test_attention_tensors_beyond_2g_elements(pkg, dev):
+    """Sized for 288 GB: q, o, dO, dq hold 2^31 + 2^26 ELEMENTS each (4.1 GiB in bf16), so every (batch, head) offset past
+    the first 2^31 elements needs 64-bit addressing.  The last (batch, kv-head) slice of the big launch -- forward and
+    backward, GQA 2:1 -- must be bitwise what a launch on that slice alone produces; a middle slice too."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs ~36 GiB of device memory")
+    dt = torch.bfloat16
+    B, QH, KH, L, E = 33, 32, 16, 16384, 128              # 33 * 32 * 16384 * 128 = 2^31 + 2^26 elements
+    assert B * QH * L * E > 2 ** 31
+    q = torch.empty(B, QH, L, E, device=dev, dtype=dt); _fill_normal(q, 1)
+    k = torch.empty(B, KH, L, E, device=dev, dtype=dt); _fill_normal(k, 2)
+    v = torch.empty(B, KH, L, E, device=dev, dtype=dt); _fill_normal(v, 3)
+    do = torch.empty(B, QH, L, E, device=dev, dtype=dt); _fill_normal(do, 4)
+    o, ms, ls = pkg._flash_attention(q, k, v, causal=True)
+    dq, dk, dv, _ = pkg.grad_flash_attention(do, o, ms, ls, q, k, v, causal=True)
+    torch.cuda.synchronize()
+    for b in (B - 1, B // 2):
+        sl = slice(b, b + 1)
+        o1, ms1, ls1 = pkg._flash_attention(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), causal=True)
+        dq1, dk1, dv1, _ = pkg.grad_flash_attention(do[sl].contiguous(), o1, ms1, ls1, q[sl].contiguous(),
+                                                    k[sl].contiguous(), v[sl].contiguous(), causal=True)
+        torch.cuda.synchronize()
+        for name, big, small in (("o", o, o1), ("ms", ms, ms1), ("ls", ls, ls1), ("dq", dq, dq1), ("dk", dk, dk1), ("dv", dv, dv1)):
+            assert torch.equal(big[sl], small), f"{name} of batch {b}"
+    assert torch.isfinite(o[-1].float()).all() and float(o[-1].float().abs().max()) > 0
+
+
+def test_row_operators_beyond_2g_elements(pkg, dev):
+    """The row-wise operators on a matrix of 2^31 + 2^20 elements: rows past element 2^31 equal a launch on those rows
+    alone (bitwise), for softmax, both norms, and RoPE on a q tensor of that size."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs ~30 GiB of device memory")
+    dt = torch.bfloat16
+    n, emb = 2 ** 19 + 256, 4096
+    assert n * emb > 2 ** 31
+    x = torch.empty(n, emb, device=dev, dtype=dt)
+    g = torch.Generator(device=dev).manual_seed(5)
+    for i in range(0, n, 2 ** 16):
+        x[i:i + 2 ** 16].copy_(torch.randn(x[i:i + 2 ** 16].shape, generator=g, device=dev))
+    w = torch.randn(emb, device=dev, generator=g); b_ = torch.randn(emb, device=dev, generator=g)
+    tail = slice(n - 300, n)
+    xt = x[tail].contiguous()
+    y = pkg.online_softmax(x)
+    assert torch.equal(y[tail], pkg.online_softmax(xt))
+    dx = pkg.grad_online_softmax(x, y)                          # any cotangent: reuse x
+    assert torch.equal(dx[tail], pkg.grad_online_softmax(xt, y[tail].contiguous()))
+    del dx
+    yr, rms = pkg._rms_norm(x, w)
+    yt, rmst = pkg._rms_norm(xt, w)
+    assert torch.equal(yr[tail], yt) and torch.equal(rms[tail], rmst)
+    yl, mu, sg = pkg._layer_norm(x, w, b_)
+    ylt, mut, sgt = pkg._layer_norm(xt, w, b_)
+    assert torch.equal(yl[tail], ylt) and torch.equal(mu[tail], mut) and torch.equal(sg[tail], sgt)
+    # pullbacks: dx rows are independent of the other rows (dw / db are sums over ALL rows: compare to fp32 torch)
+    dxr, dwr = pkg.grad_rms_norm(y, rms, x, w)
+    dxt, _ = pkg.grad_rms_norm(y[tail].contiguous(), rmst, xt, w)
+    assert torch.equal(dxr[tail], dxt)
+    ref_dw = torch.zeros(emb, device=dev, dtype=torch.float64)
+    for i in range(0, n, 2 ** 16):
+        ref_dw += (y[i:i + 2 ** 16].double() * x[i:i + 2 ** 16].double() * rms[i:i + 2 ** 16, None].double()).sum(0)
+    assert float((dwr.double() - ref_dw).abs().max() / ref_dw.abs().max()) < 1e-4
+    del dxr, yr, yl, y
+    # RoPE: q of > 2^31 elements, k small
+    Bq, QHq, Lq, D = 1, 2 ** 11 + 1, 8192, 128
+    q = x.view(-1)[: Bq * QHq * Lq * D].view(Bq, QHq, Lq, D)
+    assert q.numel() > 2 ** 31
+    kk = torch.randn(Bq, 1, Lq, D, device=dev, generator=g).to(dt)
+    cos, sin = pkg.LlamaRotaryEmbedding(D)(torch.arange(Lq, device=dev, dtype=torch.float32)[None])
+    qo, ko = pkg.llama_rope(q, kk, cos=cos, sin=sin)
+    qo1, _ = pkg.llama_rope(q[:, -1:].contiguous(), kk, cos=cos, sin=sin)
+    assert torch.equal(qo[:, -1:], qo1)
