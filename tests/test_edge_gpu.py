@@ -69,3 +69,40 @@ def test_adversarial_logits_force_the_rescale_path(pkg, dev, dt):
                 x = got.double().cpu().numpy()
                 assert np.isfinite(x).all()
                 assert np.linalg.norm(x - ref) <= (5e-2 if dt == "bf16" else 1e-2) * np.linalg.norm(ref), name
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_key_padding_beyond_the_lds_validity_words(pkg, dev, dt, causal):
+    """Key-padding masks are turned into one 64-bit validity word per 64-key tile in LDS for up to 1024 tiles
+    (kMaxMaskTiles); longer key sequences read the mask per tile instead.  KL = 65536 + 200 crosses that limit: one batch
+    is valid almost to the end (the tiles past the limit are live), one stops early, one has holes on both sides of it."""
+    import numpy as np
+    B, QH, KH, QL, KL, E = 3, 2, 1, 96, 65536 + 200, 64
+    d = make_inputs(77, B, QH, KH, QL, KL, E, dt, dev)
+    m = np.zeros((B, KL), dtype=bool)
+    m[0, : KL - 7] = True
+    m[1, :40000] = True
+    m[2] = np.random.default_rng(3).random(KL) < 0.5
+    m[2, 65500:65600] = False
+    m[2, 65700] = True
+    d["mask"] = torch.tensor(m).to(dev)
+    if causal:
+        # causal needs queries at the far end to see the long tail: QL == KL is too big for the oracle, so shift the
+        # valid keys instead -- with top-left alignment query i sees keys <= i, i.e. only the first 96 keys here
+        d["mask"][:, :4] = True
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=causal, kpad_mask=d["mask"])
+    dq, dk, dv, _ = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=causal, kpad_mask=d["mask"])
+    torch.cuda.synchronize()
+    o_ref, ms_ref, ls_ref = oracle_fwd(d, causal)
+    assert_close("o", o, o_ref, dt, floor=True)
+    lse = ms.double().cpu().numpy() + np.log(ls.double().cpu().numpy())
+    assert_close("lse", lse, ms_ref + np.log(ls_ref), dt, floor=True)
+    rq, rk, rv, _ = oracle_bwd(d, causal)
+    sc = 1.0 if dt == "f32" else 2.0
+    assert_close("dq", dq, rq, dt, sc, floor=True)
+    assert_close("dk", dk, rk, dt, sc, floor=True)
+    assert_close("dv", dv, rv, dt, sc, floor=True)
+    # masked keys get exactly zero gradient
+    dead = ~d["mask"]
+    assert (dk[dead[:, None, :].expand(B, KH, KL)] == 0).all() and (dv[dead[:, None, :].expand(B, KH, KL)] == 0).all()
