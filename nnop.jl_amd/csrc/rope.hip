@@ -16,101 +16,98 @@ struct RopeParams {
     const void *q, *k, *cos, *sin;
     int D, L, QH, KH, B;
     float sin_sign;
-    long long n_rows_q, n_rows;     // rows of q; rows of q + rows of k
+    long long n_items_q, n_items;   // work items over q; over q and k
 };
 
-// Measured on MI355X (tools/vars_rope.sh, profiles/r01/NOTES.md): U in {1,2,4} x nontemporal stores on/off are all
-// within noise of each other (5.4-5.7 TB/s at Llama-8B shapes); nontemporal LOADS cost 10 % in fp32.  Default: the
-// simplest form.
-#ifndef NNOP_ROPE_U
-#define NNOP_ROPE_U 1
+// Heads per lane.  The cos / sin half-rows of a (position, batch) are shared by every head; at D = 128 they are 512 B of
+// L2 -> L1 traffic against a 256-B bf16 row.  A lane can keep its cos / sin chunk in registers and apply it to HG heads.
+// Measured on MI355X (profiles/r01/NOTES.md): HG = 1, 2, 4, 8 are within +-5 % of each other (HG = 2: +4..10 % at B = 4,
+// -4 % at L = 32768 B = 1 where two heads are 8 MB apart) -- that traffic is not the limiter.  Default: one head.
+#ifndef NNOP_ROPE_HG
+#define NNOP_ROPE_HG 1
 #endif
-#ifndef NNOP_ROPE_NT
-#define NNOP_ROPE_NT 0
-#endif
-
-template <typename V> __device__ __forceinline__ void rope_store(V* dst, const V& v) {
-#if NNOP_ROPE_NT
-    __builtin_nontemporal_store(v, dst);          // outputs are not re-read by this kernel: keep L2 for cos/sin
-#else
-    *dst = v;
-#endif
-}
 
 // VEC: elements per lane per half (8 on the vector path, 1 on the generic path when D/2 % 8 != 0).
-// U: chunks per lane, strided by the grid so that a wave's accesses stay contiguous; all 2U row loads are issued
-// before the first use.
-template <typename T, typename CS, int VEC, int U>
+// Work item = (batch, group of HG heads, position, chunk), chunk fastest then position: a wave's lanes cover consecutive
+// chunks of consecutive rows of one head, so every load / store instruction is contiguous in memory.
+template <typename T, typename CS, int VEC, int HG>
 __global__ __launch_bounds__(256) void rope_kernel(const RopeParams p) {
     typedef T tv __attribute__((ext_vector_type(VEC)));
     typedef CS cv __attribute__((ext_vector_type(VEC)));
     const int half = p.D >> 1;
     const int cpr = half / VEC;                                   // lanes per row
-    const long long n_chunks = p.n_rows * cpr;
-    const long long stride = (long long)gridDim.x * 256;
-    const long long gid0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    tv x1[U], x2[U];
-    cv cc[U], ss[U];
-    T* y[U];
-    int c[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        long long gid = gid0 + u * stride;
-        y[u] = nullptr;
-        if (gid >= n_chunks) continue;
-        const long long row = gid / cpr;
-        c[u] = (int)(gid - row * cpr) * VEC;                      // first element of this lane's chunk
-        // row -> (tensor, batch, head, position)
-        const bool is_k = row >= p.n_rows_q;
-        const long long r = is_k ? row - p.n_rows_q : row;
-        const int H = is_k ? p.KH : p.QH;
-        const int l = (int)(r % p.L);
-        const int b = (int)(r / ((long long)p.L * H));
-        const T* __restrict__ x = (const T*)(is_k ? p.k : p.q) + r * p.D;
-        y[u] = (T*)(is_k ? p.ko : p.qo) + r * p.D;
-        const CS* __restrict__ cs = (const CS*)p.cos + ((size_t)b * p.L + l) * p.D;
-        const CS* __restrict__ sn = (const CS*)p.sin + ((size_t)b * p.L + l) * p.D;
-        if constexpr (VEC > 1) {
-            x1[u] = *reinterpret_cast<const tv*>(x + c[u]);
-            x2[u] = *reinterpret_cast<const tv*>(x + half + c[u]);
-            cc[u] = *reinterpret_cast<const cv*>(cs + c[u]);
-            ss[u] = *reinterpret_cast<const cv*>(sn + c[u]);
-        } else {
-            x1[u][0] = x[c[u]]; x2[u][0] = x[half + c[u]];
-            cc[u][0] = cs[c[u]]; ss[u][0] = sn[c[u]];
-        }
+    long long it = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (it >= p.n_items) return;
+    const bool is_k = it >= p.n_items_q;
+    if (is_k) it -= p.n_items_q;
+    const int H = is_k ? p.KH : p.QH;
+    const int n_hg = (H + HG - 1) / HG;
+    const int c = (int)(it % cpr) * VEC;                          // first element of this lane's chunk
+    long long t = it / cpr;
+    const int l = (int)(t % p.L); t /= p.L;
+    const int hg = (int)(t % n_hg);
+    const int b = (int)(t / n_hg);
+    const int h0 = hg * HG;
+    const T* __restrict__ x = (const T*)(is_k ? p.k : p.q) + (((size_t)b * H + h0) * p.L + l) * p.D;
+    T* __restrict__ y = (T*)(is_k ? p.ko : p.qo) + (((size_t)b * H + h0) * p.L + l) * p.D;
+    const size_t hstride = (size_t)p.L * p.D;
+    const CS* __restrict__ cs = (const CS*)p.cos + ((size_t)b * p.L + l) * p.D;
+    const CS* __restrict__ sn = (const CS*)p.sin + ((size_t)b * p.L + l) * p.D;
+    cv cc, ss;
+    tv x1[HG], x2[HG];
+    if constexpr (VEC > 1) {
+        cc = *reinterpret_cast<const cv*>(cs + c);
+        ss = *reinterpret_cast<const cv*>(sn + c);
+    } else {
+        cc[0] = cs[c]; ss[0] = sn[c];
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        if (!y[u]) continue;
-        tv o1, o2;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const float a = to_f32(x1[u][j]), bq = to_f32(x2[u][j]);
-            const float co = to_f32(cc[u][j]), si = to_f32(ss[u][j]) * p.sin_sign;
-            o1[j] = from_f32<T>(a * co - bq * si);
-            o2[j] = from_f32<T>(bq * co + a * si);
+    for (int u = 0; u < HG; ++u) {
+        if (h0 + u < H) {
+            if constexpr (VEC > 1) {
+                x1[u] = *reinterpret_cast<const tv*>(x + u * hstride + c);
+                x2[u] = *reinterpret_cast<const tv*>(x + u * hstride + half + c);
+            } else {
+                x1[u][0] = x[u * hstride + c]; x2[u][0] = x[u * hstride + half + c];
+            }
         }
-        if constexpr (VEC > 1) {
-            rope_store(reinterpret_cast<tv*>(y[u] + c[u]), o1);
-            rope_store(reinterpret_cast<tv*>(y[u] + half + c[u]), o2);
-        } else {
-            y[u][c[u]] = o1[0];
-            y[u][half + c[u]] = o2[0];
+    }
+    float co[VEC], si[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { co[j] = to_f32(cc[j]); si[j] = to_f32(ss[j]) * p.sin_sign; }
+#pragma unroll
+    for (int u = 0; u < HG; ++u) {
+        if (h0 + u < H) {
+            tv o1, o2;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float a = to_f32(x1[u][j]), bq = to_f32(x2[u][j]);
+                o1[j] = from_f32<T>(a * co[j] - bq * si[j]);
+                o2[j] = from_f32<T>(bq * co[j] + a * si[j]);
+            }
+            if constexpr (VEC > 1) {
+                *reinterpret_cast<tv*>(y + u * hstride + c) = o1;
+                *reinterpret_cast<tv*>(y + u * hstride + half + c) = o2;
+            } else {
+                y[u * hstride + c] = o1[0];
+                y[u * hstride + half + c] = o2[0];
+            }
         }
     }
 }
 
 template <typename T, typename CS>
-static int launch_rope_t(const RopeParams& p, hipStream_t s) {
-    constexpr int U = NNOP_ROPE_U;
+static int launch_rope_t(RopeParams p, hipStream_t s) {
+    constexpr int HG = NNOP_ROPE_HG;
     const int half = p.D >> 1;
     const bool vec = (half % 8) == 0;
-    const long long n_chunks = p.n_rows * (vec ? half / 8 : half);
-    const long long grid = (n_chunks + 256LL * U - 1) / (256LL * U);
+    const long long cpr = vec ? half / 8 : half;
+    p.n_items_q = (long long)p.B * ((p.QH + HG - 1) / HG) * p.L * cpr;
+    p.n_items = p.n_items_q + (long long)p.B * ((p.KH + HG - 1) / HG) * p.L * cpr;
+    const long long grid = (p.n_items + 255) / 256;
     if (grid <= 0 || grid > 0x7fffffffLL) return NNOP_ERR_SHAPE;
-    if (vec) hipLaunchKernelGGL((rope_kernel<T, CS, 8, U>), dim3((unsigned)grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((rope_kernel<T, CS, 1, U>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    if (vec) hipLaunchKernelGGL((rope_kernel<T, CS, 8, HG>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((rope_kernel<T, CS, 1, HG>), dim3((unsigned)grid), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
@@ -120,8 +117,7 @@ int launch_rope(const nnop_rope_desc& d, void* qo, void* ko, const void* q, cons
     p.qo = qo; p.ko = ko; p.q = q; p.k = k; p.cos = cos; p.sin = sin;
     p.D = d.dim; p.L = d.seq; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
     p.sin_sign = sin_sign;
-    p.n_rows_q = (long long)d.batch * d.qh * d.seq;
-    p.n_rows = p.n_rows_q + (long long)d.batch * d.kh * d.seq;
+    p.n_items_q = p.n_items = 0;                                 // set per instantiation in launch_rope_t
     const bool cs32 = d.cs_dtype == NNOP_F32;
     switch (d.dtype) {
         case NNOP_F32:  return launch_rope_t<float, float>(p, s);

@@ -1,6 +1,9 @@
 #!/bin/bash
-# dev: time the RoPE kernel variants built into nnop.jl_amd/lib_var{1..6} (U x NT)
+# dev: time RoPE kernel variants built into nnop.jl_amd/lib_var{1..N} (e.g. heads per lane NNOP_ROPE_HG = 1, 2, 4, 8)
 cd /root/repo
-for i in 1 2 3 4 5 6; do
-  echo "var $i:"; NNOP_LIB_PATH=/root/repo/nnop.jl_amd/lib_var$i/libnnop_hip.so python tools/perf_rope.py 2>/dev/null | cut -c1-140 | grep -o '"shape.*"us": [0-9.]*\|gbps": [0-9.]*' | paste - - 
+N=${1:-4}
+for r in 1 2; do
+for i in $(seq 1 $N); do
+  echo "var $i: $(NNOP_LIB_PATH=/root/repo/nnop.jl_amd/lib_var$i/libnnop_hip.so python tools/perf_rope.py 2>/dev/null | grep -o '"shape": "[a-z0-9-]*"\|"us": [0-9.]*\|"gbps": [0-9.]*' | paste - - - | sed 's/"shape": //; s/"us": //; s/"gbps": //' | tr '\n' '|')"
+done
 done
