@@ -226,27 +226,27 @@ template <typename T, int E, int ROWS, int NT> struct Stager {
     static constexpr int kNCH = ROWS * kN16;
     static constexpr int kNLD = (kNCH + NT - 1) / NT;
     u32x4 reg[kNLD];
+    int rows_valid_ = ROWS;      // rows of the held tile that exist; the others are zeroed when the tile is WRITTEN
 
-    // gtile: address of row 0 of the tile; rows_valid: rows that exist, 1 <= rows_valid (may
-    // exceed ROWS).  Branch-free: the row index is clamped for the load and rows past the end are
-    // zeroed by a select, so no exec-masked region splits the surrounding instruction stream.
+    // gtile: address of row 0 of the tile; rows_valid: rows that exist, 1 <= rows_valid (may exceed ROWS).
+    // Branch-free: the row index is clamped for the load, so no exec-masked region splits the surrounding instruction
+    // stream.  Rows past the end are zero-filled by write(), NOT here: a select on the loaded registers at this point
+    // would put the wait for the load right behind its issue and expose the HBM / L2 latency on every tile (measured:
+    // +20 % per tile in the masked forward, see profiles/r01/NOTES.md).
     NNOP_DEV void load(const void* gtile, int rows_valid, int tid) {
+        rows_valid_ = rows_valid;
 #pragma unroll
         for (int i = 0; i < kNLD; ++i) {
             int c = tid + i * NT;
             if (kNCH % NT != 0) c = c < kNCH ? c : kNCH - 1;          // surplus lanes re-read the last chunk
             const int row = c / kN16, c16 = c % kN16;
             const int rowc = row < rows_valid ? row : rows_valid - 1;
-            u32x4 v = *reinterpret_cast<const u32x4*>((const char*)gtile + ((size_t)rowc * kN16 + c16) * 16);
-            const bool ok = row < rows_valid;
-            reg[i][0] = ok ? v[0] : 0u;
-            reg[i][1] = ok ? v[1] : 0u;
-            reg[i][2] = ok ? v[2] : 0u;
-            reg[i][3] = ok ? v[3] : 0u;
+            reg[i] = *reinterpret_cast<const u32x4*>((const char*)gtile + ((size_t)rowc * kN16 + c16) * 16);
         }
     }
     // same, when the caller guarantees rows_valid >= ROWS (every row exists)
     NNOP_DEV void load_full(const void* gtile, int tid) {
+        rows_valid_ = ROWS;
 #pragma unroll
         for (int i = 0; i < kNLD; ++i) {
             int c = tid + i * NT;
@@ -254,11 +254,19 @@ template <typename T, int E, int ROWS, int NT> struct Stager {
             reg[i] = *reinterpret_cast<const u32x4*>((const char*)gtile + (size_t)c * 16);
         }
     }
-    template <typename Img> NNOP_DEV void write(char* img, int tid) const {
+    // ZFILL: zero the rows >= rows_valid_ of a tile fetched with load(); false for tiles fetched with load_full()
+    template <typename Img, bool ZFILL = true> NNOP_DEV void write(char* img, int tid) const {
 #pragma unroll
         for (int i = 0; i < kNLD; ++i) {
             const int c = tid + i * NT;
-            if (kNCH % NT == 0 || c < kNCH) Img::write16(img, c / kN16, c % kN16, reg[i]);
+            if (kNCH % NT == 0 || c < kNCH) {
+                u32x4 v = reg[i];
+                if constexpr (ZFILL) {
+                    const bool ok = c / kN16 < rows_valid_;
+                    v[0] = ok ? v[0] : 0u; v[1] = ok ? v[1] : 0u; v[2] = ok ? v[2] : 0u; v[3] = ok ? v[3] : 0u;
+                }
+                Img::write16(img, c / kN16, c % kN16, v);
+            }
         }
     }
 };

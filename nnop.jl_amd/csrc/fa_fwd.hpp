@@ -478,8 +478,8 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
         if (n_tiles > 0) {
             stage(sk0, kp, 0);
             stage(sv0, vp, 0);
-            sk0.template write<KImg>(kring, tid);
-            sv0.template write<VImg>(vring, tid);
+            sk0.template write<KImg, kGeneral>(kring, tid);
+            sv0.template write<VImg, kGeneral>(vring, tid);
         }
 #pragma unroll
         for (int z = 0; z < QB; ++z)
@@ -503,8 +503,8 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
                 softmax_pv(sc, vring + (t & 1) * VBYTES, vfr);
             }
             if (more1) {
-                sk0.template write<KImg>(kring + ((t + 1) & 1) * KBYTES, tid);
-                sv0.template write<VImg>(vring + ((t + 1) & 1) * VBYTES, tid);
+                sk0.template write<KImg, kGeneral>(kring + ((t + 1) & 1) * KBYTES, tid);
+                sv0.template write<VImg, kGeneral>(vring + ((t + 1) & 1) * VBYTES, tid);
             }
             __syncthreads();
         }
@@ -518,10 +518,10 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
             stage(sk0, kp, 0);
             stage(sv0, vp, 0);
             if (n_tiles > 1) stage(sk1, kp, 1);
-            sk0.template write<KImg>(kring, tid);
-            sv0.template write<VImg>(vring, tid);
+            sk0.template write<KImg, kGeneral>(kring, tid);
+            sv0.template write<VImg, kGeneral>(vring, tid);
             if (n_tiles > 1) {
-                sk1.template write<KImg>(kring + KBYTES, tid);
+                sk1.template write<KImg, kGeneral>(kring + KBYTES, tid);
                 if constexpr (kDeep) stage(sv1, vp, 1);
             }
             if constexpr (kDeep) {
@@ -598,8 +598,8 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
                 }
             }
 #if NNOP_ABL != 6
-            if (more2) skw.template write<KImg>(kring + (t & 1) * KBYTES, tid);
-            if (more1) svw.template write<VImg>(vring + ((t + 1) & 1) * VBYTES, tid);
+            if (more2) skw.template write<KImg, kGeneral>(kring + (t & 1) * KBYTES, tid);
+            if (more1) svw.template write<VImg, kGeneral>(vring + ((t + 1) & 1) * VBYTES, tid);
 #endif
 #if NNOP_ABL != 1
             __syncthreads();
