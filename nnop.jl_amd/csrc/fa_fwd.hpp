@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
     // kDeep    : HBM loads run two intervals ahead of the LDS writes (two register sets)
     // kMfmaSum : row sums on the matrix pipe
     constexpr bool k16 = sizeof(T) == 2;
-    constexpr bool kPipe = k16 && (E <= 64 || MODE == 0);
+    constexpr bool kPipe = k16 && (E <= 64 || MODE == 0);      // E = 128 masked, pipelined: 716 B/lane of spills, 2x slower
     constexpr bool kPrefetch = NNOP_V_PREFETCH && k16 && (QB == 2 ? E <= 64 : (MODE == 0 && E <= 64));
     constexpr int  PFK = kPrefetch ? (NKF <= 8 ? NKF : 8) : 0;
     constexpr int  PFV = kPrefetch ? (NVF <= 8 ? NVF : 8) : 0;
