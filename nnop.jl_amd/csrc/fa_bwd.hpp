@@ -220,19 +220,23 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     const int n_it = nqt * rep;
 
     Stager<T, E, BQ, NT> sq, sdo;
-    float rowc = 0.f;                                     // nl (tid < BQ) or delta (BQ <= tid < 2BQ)
+    // Row constants of the tile: nl (tid < BQ) or delta (BQ <= tid < 2BQ).  Loaded UNCONDITIONALLY from a clamped
+    // address and turned into the stored value (sign, -inf / 0 for rows past QL) only in stage_write: a load inside a
+    // divergent branch whose result merges with a constant makes the compiler wait for it at the end of the branch,
+    // i.e. right behind the tile loads issued above -- the whole memory latency exposed once per q tile.
+    float rowc_raw = 0.f;
+    bool rowc_in = false;
+    const float* __restrict__ rowc_src = tid < BQ ? p.nl : p.delta;
+    const int rowc_rr = tid < BQ ? tid : (tid < 2 * BQ ? tid - BQ : 0);
     auto stage_load = [&](int it) {
         const int g = it / nqt, qt = qt0 + it - g * nqt;
         const int qh = kvh * rep + g;
         const size_t row0 = (size_t)(b * p.QH + qh) * p.QL + (size_t)qt * BQ;
         sq.load((const T*)p.q + row0 * E, p.QL - qt * BQ, tid);
         sdo.load((const T*)p.d_o + row0 * E, p.QL - qt * BQ, tid);
-        if (tid < 2 * BQ) {
-            const int rr = tid < BQ ? tid : tid - BQ;
-            const bool in = qt * BQ + rr < p.QL;
-            if (tid < BQ) rowc = in ? p.nl[row0 + rr] : -INFINITY;
-            else rowc = in ? -p.delta[row0 + rr] : 0.f;
-        }
+        const int last = p.QL - 1 - qt * BQ;               // last existing row of this tile (>= 0)
+        rowc_in = rowc_rr <= last;
+        rowc_raw = rowc_src[row0 + (rowc_in ? rowc_rr : last)];
     };
     auto stage_write = [&](char* buf) {
         sq.template write<Row>(buf, tid);
@@ -241,7 +245,10 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             sq.template write<Col>(buf + Row::bytes(BQ), tid);
             sdo.template write<Col>(buf + QIMG + Row::bytes(BQ), tid);
         }
-        if (tid < 2 * BQ) reinterpret_cast<float*>(buf + 2 * QIMG)[tid] = rowc;
+        if (tid < 2 * BQ) {
+            const float rowc = tid < BQ ? (rowc_in ? rowc_raw : -INFINITY) : (rowc_in ? -rowc_raw : 0.f);
+            reinterpret_cast<float*>(buf + 2 * QIMG)[tid] = rowc;
+        }
     };
 
     f32x16 dka[EB], dva[EB];
