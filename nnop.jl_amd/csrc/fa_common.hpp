@@ -293,8 +293,14 @@ NNOP_DEV int kpad_scan(const uint8_t* __restrict__ mp, int KL, int nkeys, uint64
 #pragma unroll
             for (int j = 0; j < 16; ++j) bits |= (((v[j >> 2] >> (8 * (j & 3))) & 0xffu) != 0u ? 1u : 0u) << j;
         } else {
+            // unaligned row (KL not a multiple of 16) or the row's tail: 16 independent byte loads from clamped
+            // addresses, combined afterwards -- one wait, not one per byte
+            uint8_t by[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) by[j] = mp[k0 + j < KL ? k0 + j : KL - 1];
+#pragma unroll
             for (int j = 0; j < 16; ++j)
-                if (k0 + j < KL && mp[k0 + j] != 0) bits |= 1u << j;
+                if (k0 + j < KL && by[j] != 0) bits |= 1u << j;
         }
         if (k0 + 16 > nkeys) bits &= (k0 < nkeys) ? ((1u << (nkeys - k0)) - 1u) : 0u;
         if (c < 4 * max_words) w16[c] = (uint16_t)bits;
