@@ -31,6 +31,7 @@
 // S and dP are recomputed in both kernels (7 products instead of 5): the price of having no
 // cross-workgroup dQ reduction (f32 atomics would bound the pass at ~1.3 TB/s of added bytes).
 #pragma once
+#include <type_traits>
 #include "fa_common.hpp"
 
 namespace nnop {
@@ -319,25 +320,32 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                 pbase = (const T*)p.pair + (((size_t)b * p.KL + key_c) * p.QL + q0) * p.QH + qh;
                 qmax = p.QL - 1 - q0;                                      // last in-range local query row
             }
+            // The key sits on the lane and every product contracts over QUERIES, so a masked-out key only ever
+            // pollutes its own lane's dK / dV rows: key validity costs nothing here (those rows are zeroed before the
+            // store).  Only the causal diagonal needs a per-element select, and only in diagonal blocks (wave-uniform).
             f32x16 ds;
+            auto p_ds = [&](auto masked) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float x = s[i] * c2;
-                const int lrow = acc_row(i, h);
-                const int qrow_i = q0 + lrow;
-                bool ok = true;
-                if constexpr (kGeneral) {
-                    ok = kvalid;
-                    if (diag) ok = ok && (qrow_i >= key);
+                for (int i = 0; i < 16; ++i) {
+                    float x = s[i] * c2;
+                    const int lrow = acc_row(i, h);
                     if constexpr (kPair) {
                         const int lr = lrow < qmax ? lrow : qmax;            // clamped: always inside the tensor
                         x += to_f32(pbase[lr * p.QH]) * kLog2e;
                     }
+                    float pr = fast_exp2(x);
+                    if constexpr (decltype(masked)::value) pr = (!diag || q0 + lrow >= key) ? pr : 0.f;
+                    s[i] = pr;
+                    ds[i] = pr * dp[i];
                 }
-                float pr = fast_exp2(x);
-                if constexpr (kGeneral) pr = ok ? pr : 0.f;
-                s[i] = pr;
-                ds[i] = pr * dp[i];
+            };
+            if constexpr (kPair) {
+                p_ds(std::true_type{});                       // one body: the pair gather is not duplicated
+            } else if constexpr (kGeneral) {
+                if (diag) p_ds(std::true_type{});
+                else p_ds(std::false_type{});
+            } else {
+                p_ds(std::false_type{});
             }
             const frag_t p0 = acc_frag<T, 0>(s), p1 = acc_frag<T, 1>(s);
             const frag_t d0 = acc_frag<T, 0>(ds), d1 = acc_frag<T, 1>(ds);
@@ -368,6 +376,14 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     }
 
     if (key < p.KL) {
+        if constexpr (kGeneral) {
+            if (!kvalid) {                                  // padded-out key: its lane accumulated garbage (see above)
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { dka[eb][i] = 0.f; dva[eb][i] = 0.f; }
+            }
+        }
         const size_t ro = ((size_t)(b * p.KH + kvh) * p.KL + key) * E;
         store_acc_row<T, E>((T*)p.dk + ro, dka, p.scale, h);
         store_acc_row<T, E>((T*)p.dv + ro, dva, 1.0f, h);
@@ -568,12 +584,13 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                     dpbase = (T*)p.dpair + po;
                 }
                 f32x16 ds;
+                // masked / plain body chosen per tile (wave-uniform `need_mask`): a fully valid, unclipped tile pays no select
+                auto p_ds = [&](auto masked) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float x = s[i] * c2;
-                    bool ok = true;
-                    if constexpr (kGeneral) {
-                        if (need_mask) {
+                    for (int i = 0; i < 16; ++i) {
+                        float x = s[i] * c2;
+                        bool ok = true;
+                        if constexpr (decltype(masked)::value) {
                             const int lr = (i & 3) + 8 * (i >> 2);
                             ok = (w >> lr) & 1u;
                             if (p.causal) ok = ok && (lr <= lim);
@@ -583,15 +600,23 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                                 x += to_f32(pbase[kl * kstride]) * kLog2e;
                             }
                         }
+                        float pr = fast_exp2(x);
+                        if constexpr (decltype(masked)::value) pr = ok ? pr : 0.f;
+                        ds[i] = pr * dp[i];
+                        if constexpr (kPair) {
+                            // dpair = dS (the reference's dS / scale, src/attention_bwd.jl:123-132); lanes = consecutive queries
+                            const int klr = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            if (klr <= kmax && qi < p.QL) dpbase[klr * kstride] = from_f32<T>(ds[i]);
+                        }
                     }
-                    float pr = fast_exp2(x);
-                    if constexpr (kGeneral) pr = ok ? pr : 0.f;
-                    ds[i] = pr * dp[i];
-                    if constexpr (kPair) {
-                        // dpair = dS (the reference's dS / scale, src/attention_bwd.jl:123-132); lanes = consecutive queries
-                        const int klr = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (klr <= kmax && qi < p.QL) dpbase[klr * kstride] = from_f32<T>(ds[i]);
-                    }
+                };
+                if constexpr (kPair) {
+                    p_ds(std::true_type{});                   // need_mask is always set with a pair bias
+                } else if constexpr (kGeneral) {
+                    if (need_mask) p_ds(std::true_type{});
+                    else p_ds(std::false_type{});
+                } else {
+                    p_ds(std::false_type{});
                 }
                 const frag_t d0 = acc_frag<T, 0>(ds), d1 = acc_frag<T, 1>(ds);
 #pragma unroll
