@@ -106,3 +106,37 @@ def test_key_padding_beyond_the_lds_validity_words(pkg, dev, dt, causal):
     # masked keys get exactly zero gradient
     dead = ~d["mask"]
     assert (dk[dead[:, None, :].expand(B, KH, KL)] == 0).all() and (dv[dead[:, None, :].expand(B, KH, KL)] == 0).all()
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_masked_keys_with_overflowing_values_do_not_leak(pkg, dev, dt, causal):
+    """Padded-out keys carry huge K / V values (their unmasked logits overflow exp2 to +inf).  The dK/dV kernel lets a
+    masked key accumulate whatever it likes in its OWN lane and zeroes that lane before the store, so nothing may leak:
+    every output and gradient is finite, equals the oracle, and the masked keys' dK / dV are exactly zero."""
+    import numpy as np
+    B, QH, KH, QL, KL, E = 2, 4, 2, 200, 333, 64
+    d = make_inputs(91, B, QH, KH, QL, KL, E, dt, dev)
+    m = np.random.default_rng(7).random((B, KL)) < 0.6
+    m[:, 0] = True
+    m[1, 100:180] = False                                    # a whole 64-key tile of dead keys inside
+    d["mask"] = torch.tensor(m).to(dev)
+    dead = ~d["mask"]
+    big = 3.0e4 if dt == "bf16" else 1.0e6
+    with torch.no_grad():
+        d["k"][dead[:, None, :].expand(B, KH, KL)] = big     # q.k * scale ~ +-1e4 * sqrt(E): exp2 overflows
+        d["v"][dead[:, None, :].expand(B, KH, KL)] = -big
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=causal, kpad_mask=d["mask"])
+    dq, dk, dv, _ = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=causal, kpad_mask=d["mask"])
+    torch.cuda.synchronize()
+    for t in (o, dq, dk, dv):
+        assert torch.isfinite(t.float()).all()
+    o_ref, _, _ = oracle_fwd(d, causal)
+    rq, rk, rv, _ = oracle_bwd(d, causal)
+    sc = 1.0 if dt == "f32" else 2.0
+    assert_close("o", o, o_ref, dt, floor=True)
+    assert_close("dq", dq, rq, dt, sc, floor=True)
+    live = d["mask"][:, None, :, None].expand(B, KH, KL, E).cpu().numpy()
+    assert_close("dk", np.where(live, dk.double().cpu().numpy(), 0.0), np.where(live, rk, 0.0), dt, sc, floor=True)
+    assert_close("dv", np.where(live, dv.double().cpu().numpy(), 0.0), np.where(live, rv, 0.0), dt, sc, floor=True)
+    assert (dk[dead[:, None, :].expand(B, KH, KL)] == 0).all() and (dv[dead[:, None, :].expand(B, KH, KL)] == 0).all()
