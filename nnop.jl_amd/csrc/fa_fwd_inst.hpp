@@ -98,11 +98,13 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     if (wg256 < 256 || d.ql <= 128) nw = 4;
     // causal, E <= 64: the waves of a 256-row workgroup see 1..4 x the keys of its first wave and wait for the last one
     // at every barrier; 128-row workgroups waste half as much.  Measured (bf16, MI355X): E64 L4096 H16 B4 356 -> 304 us
-    // (+17 %).  Only while that still leaves >= 2 workgroups per CU.  Not at E = 128: there the 8-wave form is equal
-    // (C3: 5.60 vs 5.62-5.70 ms) or better (C5 shard: 20.4 vs 21.2-21.6 ms).
-    if constexpr (E <= 64) {
+    // (+17 %).  Only while that still leaves >= 2 workgroups per CU.  At E = 128 and long sequences the 8-wave form is
+    // equal (C3: 5.60 vs 5.62-5.70 ms) or better (C5 shard: 20.4 vs 21.2-21.6 ms).
+    // At E = 128 only for short sequences (QL <= 2048: L1024 314 -> 269 us, L2048 485 -> 469 us; from L4096 on the 8-wave
+    // form wins: 723 vs 762-858 us).
+    {
         const long long wg128 = (long long)((d.ql + 127) / 128) * d.qh * d.batch;
-        if (d.causal && wg128 >= 512) nw = 4;
+        if (d.causal && wg128 >= 512 && (E <= 64 || d.ql <= 2048)) nw = 4;
     }
     if (E >= 128 && mode == 2) nw = 4;               // the E=128 pair-bias body: 4 waves per workgroup
     nw = env_int("NNOP_FWD_NW", nw);
