@@ -1,0 +1,11 @@
+#!/bin/bash
+# dev: rocprofv3 per-kernel averages of tools/perf_pair.py (pair-bias forward / backward)
+cd /root/repo; export TMPDIR=/tmp
+rm -rf gpurun_out/pk; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pk -- python3 tools/perf_pair.py > /dev/null 2>&1
+python3 - <<'PY'
+import csv, glob
+f = sorted(glob.glob("/root/repo/gpurun_out/pk/*/*_kernel_stats.csv"))[-1]
+for r in csv.DictReader(open(f)):
+    if "nnop" in r["Name"] or "fill" in r["Name"].lower() or "memset" in r["Name"].lower():
+        print(f'{r["Name"][:100]:100s} calls {r["Calls"]:>4s} avg {float(r["AverageNs"])/1e3:9.1f} us')
+PY
