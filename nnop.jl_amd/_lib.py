@@ -50,6 +50,12 @@ EXPORTED_SYMBOLS = (
 )
 
 
+# Test-only hooks (csrc/nnop_debug.h): exported by the library, deliberately NOT in the public header.
+DEBUG_SYMBOLS = ("nnop_debug_set", "nnop_debug_dev_build")
+# keys of nnop_debug_set == enum TuneKey (csrc/tuning.hpp)
+TUNE_KEYS = {"fwd_split": 0, "fwd_nw": 1, "fwd_w64": 2, "bwd_big7": 3, "norm_bwd_cap": 4, "bwd_form": 5}
+
+
 class FaDesc(C.Structure):
     """struct nnop_fa_desc"""
     _fields_ = [
@@ -126,6 +132,10 @@ def load():
     lib.nnop_strerror.argtypes = [C.c_int]
     lib.nnop_abi_version.restype = C.c_int
     lib.nnop_abi_version.argtypes = []
+    lib.nnop_debug_set.restype = C.c_int
+    lib.nnop_debug_set.argtypes = [C.c_int, C.c_int]
+    lib.nnop_debug_dev_build.restype = C.c_int
+    lib.nnop_debug_dev_build.argtypes = []
     if lib.nnop_abi_version() != ABI_VERSION:
         raise NNopLibraryMissing(f"{LIB_PATH} has ABI version {lib.nnop_abi_version()}, this binding needs "
                                  f"{ABI_VERSION}: rebuild with `make -C nnop.jl_amd/csrc -j8`")
@@ -135,3 +145,15 @@ def load():
 
 def strerror(status: int) -> str:
     return load().nnop_strerror(int(status)).decode()
+
+
+def debug_set(key: str, value: int) -> int:
+    """Test-only: override one launch-shape knob (csrc/tuning.hpp); -1 = automatic.  Returns the previous value."""
+    prev = load().nnop_debug_set(TUNE_KEYS[key], int(value))
+    if prev == -(2 ** 31):
+        raise KeyError(key)
+    return prev
+
+
+def dev_build() -> bool:
+    return bool(load().nnop_debug_dev_build())

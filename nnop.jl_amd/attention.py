@@ -192,6 +192,17 @@ def grad_flash_attention(dO, o, ms, ls, q, k, v, pair=None, *, causal: bool, kpa
     dO, o, ms, ls = dO.contiguous(), o.contiguous(), ms.contiguous(), ls.contiguous()
     if dO.dtype != q.dtype or dO.shape != q.shape:
         raise TypeError("cotangent must have the dtype and shape of the output")
+    # residuals of the forward: typed like the reference's signature (o::AbstractArray{T,4}, ms/ls::AbstractArray{T,3},
+    # src/attention_bwd.jl:199-207) -- the kernels read them as T with these shapes
+    B, QH, QL, _ = q.shape
+    if o.dtype != q.dtype or o.shape != q.shape or o.device != q.device:
+        raise TypeError("`o` must have the dtype, shape and device of `q`")
+    for name, t in (("ms", ms), ("ls", ls)):
+        if t.dtype != q.dtype or tuple(t.shape) != (B, QH, QL) or t.device != q.device:
+            raise TypeError(f"`{name}` must be a [B, QH, QL] = {(B, QH, QL)} tensor of q's dtype on q's device, "
+                            f"got {tuple(t.shape)} {t.dtype}")
+    if dO.device != q.device:
+        raise TypeError("cotangent must live on q's device")
     pair = pair.contiguous() if pair is not None else None
     kpad_mask = kpad_mask.contiguous() if kpad_mask is not None else None
     d = _desc(q, k, v, causal)

@@ -80,7 +80,8 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         const size_t bytes = (size_t)d.batch * d.kl * d.ql * d.qh * sizeof(T);
         if (hipMemsetAsync(p.dpair, 0, bytes, s) != hipSuccess) { (void)hipGetLastError(); return NNOP_ERR_HIP; }
     }
-    const int big_thr = env_int("NNOP_BWD_BIG7", 512);     // workgroups (7-wave form) from which it is used
+    const int big_tune = tune_get(kTuneBwdBig7);
+    const int big_thr = big_tune >= 0 ? big_tune : 512;    // workgroups (7-wave form) from which it is used
     // 3. dK, dV
     {
         int st = NNOP_OK;

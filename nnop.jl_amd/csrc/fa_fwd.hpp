@@ -37,13 +37,24 @@
 #include <type_traits>
 #include "fa_common.hpp"
 
-// Timing-only ablation builds (make ABL=n OUTDIR=../lib_abl<n>): results are WRONG by construction.
+// Timing-only ablation builds (make DEV=1 ABL=n OUTDIR=../lib_abl<n>): results are WRONG by construction.
 //   1 no per-interval barrier   2 no exp   3 no PV MFMAs   4 no QK^T MFMAs   5 no LDS fragment reads
 //   6 no HBM->LDS staging       7 no row-sum MFMAs          8 no row max
+// The release build (no NNOP_DEV_BUILD) pins NNOP_ABL to 0: none of that code exists in the shipped library.
+#if !defined(NNOP_DEV_BUILD)
+#undef NNOP_ABL
+#endif
 #ifndef NNOP_ABL
 #define NNOP_ABL 0
 #endif
-// Variant switches for A/B timing (make VAR="-DNNOP_V_...=0"); defaults are the shipped configuration.
+// Variant switches for A/B timing (make DEV=1 VAR="-DNNOP_V_...=0"); defaults are the shipped configuration and the
+// only one a release build can have.
+#if !defined(NNOP_DEV_BUILD)
+#undef NNOP_V_PREFETCH
+#undef NNOP_V_DEEP
+#undef NNOP_V_MFMASUM
+#undef NNOP_V_SETPRIO
+#endif
 #ifndef NNOP_V_PREFETCH
 #define NNOP_V_PREFETCH 1
 #endif
@@ -76,7 +87,9 @@ struct FwdParams {
     int   n_qblk;            // ceil(QL / (32*QB*NW))
     int   n_wg;              // n_qblk * QH * B
     float scale;             // 1/sqrt(E)
-    int   stagger;           // experiment: s_sleep units for the odd co-resident workgroup (0 = off)
+#ifdef NNOP_DEV_BUILD
+    int   stagger = 0;       // experiment: s_sleep units for the odd co-resident workgroup (0 = off)
+#endif
 };
 
 // MODE 0: plain   -- KL % BK == 0, no causal, no kpad, no pair: every logit is live
@@ -120,6 +133,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
+#ifdef NNOP_DEV_BUILD
     // experiment (NNOP_FWD_STAGGER): de-phase co-resident workgroups.  HW_ID.TG_ID (bits 19:16) numbers the
     // workgroups resident on this CU; the odd one starts late so that its LDS / barrier phases fall into
     // the other's MFMA phase.  Timing only, never correctness.
@@ -127,6 +141,7 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
         const unsigned tg = __builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11));
         if (tg & 1) for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(8);
     }
+#endif
 
     // ---- which (batch, q-head, q-block) -------------------------------------------------
     int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_qblk * (p.QH / p.KH));

@@ -7,11 +7,22 @@
 // workgroup is chosen, from how many workgroups the problem yields against the chip's 256 CUs.
 #pragma once
 #include "fa_fwd.hpp"
-#include "fa_fwd_split16.hpp"
+#include "fa_fwd_split.hpp"
+#ifdef NNOP_DEV_BUILD
+#include "fa_fwd_split16.hpp"      // measured 7 % slower than the 32x32x16 body: experiments only (make DEV=1)
+#include <stdlib.h>
+#endif
 #include "fa_launch.hpp"
 #include <math.h>
 
 namespace nnop {
+
+#ifdef NNOP_DEV_BUILD
+static inline int dev_env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+#endif
 
 template <typename T, int E, int NW, int MODE, int QB>
 static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
@@ -34,9 +45,18 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.n_wg = (int)n_wg;
     p.scale = (float)(1.0 / sqrt((double)E));        // T(inv(sqrt(QE))), src/attention.jl:154
-    p.stagger = env_int("NNOP_FWD_STAGGER", 0);
-    const int lds_pad = env_int("NNOP_FWD_LDS_PAD", 0);   // debugging aid: limits workgroups per CU
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds + lds_pad, s, p);
+    int lds_launch = lds;
+#ifdef NNOP_DEV_BUILD
+    // experiments (make DEV=1 only): de-phase co-resident workgroups; pad LDS to limit workgroups per CU
+    p.stagger = dev_env_int("NNOP_FWD_STAGGER", 0);
+    lds_launch += dev_env_int("NNOP_FWD_LDS_PAD", 0);
+    if (lds_launch > lds && lds_launch > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_launch) != hipSuccess) {
+        (void)hipGetLastError();
+        return NNOP_ERR_HIP;
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds_launch, s, p);
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
@@ -44,11 +64,17 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
 // M16: the v_mfma_f32_16x16x32 body (E a multiple of 32), else the 32x32x16 body.
 template <typename T, int E, bool M16>
 static int launch_fwd_split(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+#ifdef NNOP_DEV_BUILD
     constexpr int lds = M16 ? fa_fwd_split16_lds_bytes<T, (M16 ? E : 32)>() : fa_fwd_split_lds_bytes<T, E>();
-    static_assert(lds <= 160 * 1024, "LDS budget");
     void (*kern)(const FwdParams);
     if constexpr (M16) kern = fa_fwd_split16_kernel<T, E>;
     else kern = fa_fwd_split_kernel<T, E>;
+#else
+    static_assert(!M16, "the 16x16x32 body is compiled under make DEV=1 only");
+    constexpr int lds = fa_fwd_split_lds_bytes<T, E>();
+    void (*kern)(const FwdParams) = fa_fwd_split_kernel<T, E>;
+#endif
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static unsigned long long lds_done = 0;
     if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
     FwdParams p;
@@ -61,7 +87,6 @@ static int launch_fwd_split(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t
     if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.n_wg = (int)n_wg;
     p.scale = (float)(1.0 / sqrt((double)E));
-    p.stagger = 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(1024), lds, s, p);
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
@@ -82,15 +107,15 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
     if constexpr (sizeof(T) == 2 && E <= 64) {
         // default for plain mode: 16-wave split-KV workgroups (4 waves per SIMD); measured 5-13 % faster than
-        // the 8-wave form from 64 to 4096 workgroups.  NNOP_FWD_SPLIT=0 disables.
-        // NNOP_FWD_SPLIT: 0 off; 1 (default) the 32x32x16 body; 16 the v_mfma_16x16x32 body (fa_fwd_split16.hpp) --
-        // correct and tested, measured 7 % SLOWER at C2 (twice the MFMA issues, two extra cross-lane steps per row max;
-        // this kernel is issue-bound, not MFMA-clock-bound -- DESIGN.md section 5), so opt-in only.
-        const int split = env_int("NNOP_FWD_SPLIT", 1);
-        if (mode == 0 && d.ql > 128 && d.kl >= 128 && split) {
+        // the 8-wave form from 64 to 4096 workgroups.  Knob kTuneFwdSplit: 0 off, 1 / auto on;
+        // 16 (make DEV=1 builds only) the v_mfma_16x16x32 body of fa_fwd_split16.hpp -- correct, measured 7 % SLOWER.
+        const int split = tune_get(kTuneFwdSplit);
+        if (mode == 0 && d.ql > 128 && d.kl >= 128 && split != 0) {
+#ifdef NNOP_DEV_BUILD
             if constexpr (E % 32 == 0) {
                 if (split == 16) return launch_fwd_split<T, E, true>(d, a, s);
             }
+#endif
             return launch_fwd_split<T, E, false>(d, a, s);
         }
     }
@@ -107,15 +132,15 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
         if (d.causal && wg128 >= 512 && (E <= 64 || d.ql <= 2048)) nw = 4;
     }
     if (E >= 128 && mode == 2) nw = 4;               // the E=128 pair-bias body: 4 waves per workgroup
-    nw = env_int("NNOP_FWD_NW", nw);
-    // QB = 2 (4 waves x 64 rows, one wave per SIMD) is EXPERIMENTAL and opt-in: it halves the LDS
-    // fragment traffic per MFMA, but hipcc's allocator then shuttles the score tiles between AGPRs
-    // and VGPRs (~440 v_accvgpr moves per kv tile) and it runs 1.3x SLOWER than QB = 1 (measured,
-    // DESIGN.md section 6).  Plain mode, E <= 64 only.
-    qb = env_int("NNOP_FWD_QB", qb);
+    if (const int t = tune_get(kTuneFwdNW); t == 4 || t == 8) nw = t;
+#ifdef NNOP_DEV_BUILD
+    // QB = 2 with builtin MFMAs (experiment, make DEV=1): hipcc shuttles the score tiles between AGPRs and VGPRs
+    // (~440 v_accvgpr moves per kv tile), 1.3x slower than QB = 1.  The shipped 64-row form is fa_fwd_w64.hpp.
+    qb = dev_env_int("NNOP_FWD_QB", qb);
     if constexpr (sizeof(T) == 2 && E <= 64) {
         if (qb == 2 && mode == 0) return launch_fwd_cfg<T, E, 4, 0, 2>(d, a, s);
     }
+#endif
     if (nw == 8) return launch_fwd_mode<T, E, 8, 1>(d, a, s, mode);
     return launch_fwd_mode<T, E, 4, 1>(d, a, s, mode);
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/nnop_hip.h"
+#include "tuning.hpp"
 
 namespace nnop {
 
@@ -51,8 +52,6 @@ inline size_t bwd_workspace_bytes(const nnop_fa_desc& d) {
     return 2 * (size_t)d.batch * d.qh * d.ql * sizeof(float);
 }
 
-// Optional tuning override (read-only environment): workgroup waves for the forward.
-int env_int(const char* name, int dflt);
 
 // Kernels that need more than 64 KiB of dynamic LDS must opt in once per (kernel, device).  `done` is a per-kernel
 // static bitmap (one bit per device ordinal < 64); setting the attribute twice is harmless, so a benign race between

@@ -5,13 +5,28 @@
 // become status codes; allocation of outputs and scratch moves to the caller; the launch is
 // asynchronous on the caller's stream (src/attention.jl:170-176 never synchronises either).
 #include "fa_launch.hpp"
+#include "nnop_debug.h"
+#include "tuning.hpp"
+#include <limits.h>
 #include <stdlib.h>
+#include <mutex>
 
 namespace nnop {
-int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    if (!s || !*s) return dflt;
-    return atoi(s);
+
+// ---- launch-shape overrides (tuning.hpp): environment parsed once, then a table of ints ------------
+static int g_tune[kTuneCount];
+static std::once_flag g_tune_once;
+static void tune_init() {
+    static const char* const names[kTuneCount] = {"NNOP_FWD_SPLIT", "NNOP_FWD_NW",       "NNOP_FWD_W64",
+                                                  "NNOP_BWD_BIG7",  "NNOP_NORM_BWD_CAP", "NNOP_BWD_FORM"};
+    for (int k = 0; k < kTuneCount; ++k) {
+        const char* s = getenv(names[k]);
+        __atomic_store_n(&g_tune[k], (s && *s) ? atoi(s) : -1, __ATOMIC_RELAXED);
+    }
+}
+int tune_get(int key) {
+    std::call_once(g_tune_once, tune_init);
+    return __atomic_load_n(&g_tune[key], __ATOMIC_RELAXED);
 }
 
 static int check_desc(const nnop_fa_desc* d) {
@@ -32,6 +47,11 @@ static int check_desc(const nnop_fa_desc* d) {
     if ((long long)d->ql * d->emb > 0x7fffffffLL || (long long)d->kl * d->emb > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     return NNOP_OK;
 }
+// pair / dpair [B][KL][QL][QH]: inside one kv tile the kernels address the bias with 32-bit element offsets
+// (local key < 64) * QL * QH
+static int check_pair(const nnop_fa_desc* d) {
+    return ((long long)d->ql * d->qh * 64 > 0x7fffffffLL) ? NNOP_ERR_SHAPE : NNOP_OK;
+}
 }  // namespace nnop
 
 using namespace nnop;
@@ -39,6 +59,20 @@ using namespace nnop;
 extern "C" {
 
 int nnop_abi_version(void) { return NNOP_HIP_ABI_VERSION; }
+
+// test-only hooks, declared in csrc/nnop_debug.h (not in the public header)
+int nnop_debug_set(int key, int value) {
+    if (key < 0 || key >= kTuneCount) return INT_MIN;
+    (void)tune_get(key);                                   // make sure the environment has been parsed first
+    return __atomic_exchange_n(&g_tune[key], value, __ATOMIC_RELAXED);
+}
+int nnop_debug_dev_build(void) {
+#ifdef NNOP_DEV_BUILD
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 const char* nnop_strerror(int status) {
     switch (status) {
@@ -75,6 +109,7 @@ int nnop_fa_fwd(const nnop_fa_desc* d, void* o, void* ms, void* ls, const void* 
     const int st = check_desc(d);
     if (st != NNOP_OK) return st;
     if (!o || !ms || !ls || !q || !k || !v) return NNOP_ERR_NULL;
+    if (pair && check_pair(d) != NNOP_OK) return NNOP_ERR_SHAPE;
     FwdArgs a{o, ms, ls, q, k, v, pair, kpad_mask};
     hipStream_t s = (hipStream_t)stream;
     switch (d->dtype) {
@@ -178,6 +213,7 @@ int nnop_fa_bwd(const nnop_fa_desc* d, void* dq, void* dk, void* dv, void* dpair
     if (st != NNOP_OK) return st;
     if (!dq || !dk || !dv || !d_o || !o || !ms || !ls || !q || !k || !v || !workspace) return NNOP_ERR_NULL;
     if (pair && !dpair) return NNOP_ERR_NULL;
+    if (pair && check_pair(d) != NNOP_OK) return NNOP_ERR_SHAPE;
     if (workspace_bytes < bwd_workspace_bytes(*d)) return NNOP_ERR_WORKSPACE;
     BwdArgs a{dq, dk, dv, dpair, d_o, o, ms, ls, q, k, v, pair, kpad_mask, workspace};
     hipStream_t s = (hipStream_t)stream;

@@ -360,7 +360,7 @@ static inline long long norm_bwd_max_parts(long long n) {
 static inline int norm_bwd_parts(long long n, int emb, int rpb) {
     long long cap = (2LL << 20) / emb;
     cap = cap < 256 ? 256 : (cap > kNormBwdCap ? kNormBwdCap : cap);
-    cap = env_int("NNOP_NORM_BWD_CAP", (int)cap);
+    if (const int t = tune_get(kTuneNormBwdCap); t > 0) cap = t;
     long long wgs = (n + (long long)rpb * 4 - 1) / ((long long)rpb * 4);
     if (wgs > cap) wgs = cap;
     if (wgs > norm_bwd_max_parts(n)) wgs = norm_bwd_max_parts(n);

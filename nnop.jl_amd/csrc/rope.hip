@@ -56,8 +56,18 @@ __global__ __launch_bounds__(256) void rope_kernel(const RopeParams p) {
     cv cc, ss;
     tv x1[HG], x2[HG];
     if constexpr (VEC > 1) {
-        cc = *reinterpret_cast<const cv*>(cs + c);
-        ss = *reinterpret_cast<const cv*>(sn + c);
+        // 16-byte accesses only: an 8 x fp32 chunk is loaded as two 16-byte halves, so 16-byte alignment of the
+        // tensors (checked by the launcher) is all the vector path needs
+        typedef CS ch __attribute__((ext_vector_type(sizeof(CS) == 4 ? VEC / 2 : VEC)));
+        if constexpr (sizeof(CS) == 4) {
+            const ch c0 = *reinterpret_cast<const ch*>(cs + c), c1 = *reinterpret_cast<const ch*>(cs + c + VEC / 2);
+            const ch s0 = *reinterpret_cast<const ch*>(sn + c), s1 = *reinterpret_cast<const ch*>(sn + c + VEC / 2);
+#pragma unroll
+            for (int j = 0; j < VEC / 2; ++j) { cc[j] = c0[j]; cc[VEC / 2 + j] = c1[j]; ss[j] = s0[j]; ss[VEC / 2 + j] = s1[j]; }
+        } else {
+            cc = *reinterpret_cast<const ch*>(cs + c);
+            ss = *reinterpret_cast<const ch*>(sn + c);
+        }
     } else {
         cc[0] = cs[c]; ss[0] = sn[c];
     }
@@ -100,7 +110,12 @@ template <typename T, typename CS>
 static int launch_rope_t(RopeParams p, hipStream_t s) {
     constexpr int HG = NNOP_ROPE_HG;
     const int half = p.D >> 1;
-    const bool vec = (half % 8) == 0;
+    // the vector path issues 16-byte loads / stores: every tensor must be 16-byte aligned (rows then are, since
+    // D % 16 == 0 there); an offset view from a C or Julia caller takes the element-wise kernel instead
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.q) | reinterpret_cast<uintptr_t>(p.k) |
+                           reinterpret_cast<uintptr_t>(p.qo) | reinterpret_cast<uintptr_t>(p.ko) |
+                           reinterpret_cast<uintptr_t>(p.cos) | reinterpret_cast<uintptr_t>(p.sin)) & 15) == 0;
+    const bool vec = (half % 8) == 0 && aligned;
     const long long cpr = vec ? half / 8 : half;
     p.n_items_q = (long long)p.B * ((p.QH + HG - 1) / HG) * p.L * cpr;
     p.n_items = p.n_items_q + (long long)p.B * ((p.KH + HG - 1) / HG) * p.L * cpr;

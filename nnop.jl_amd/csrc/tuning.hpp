@@ -1,0 +1,28 @@
+// tuning.hpp -- launch-shape overrides, parsed ONCE.
+//
+// The launchers never call getenv(): the NNOP_* environment variables below are read a single time
+// (std::call_once, at the first launch of the process) into a small table of ints; after that a
+// changed environment has no effect and a launch costs one relaxed atomic load per knob.  The
+// table can also be written through `nnop_debug_set` (nnop_debug.h) -- a hook for the test-suite,
+// which has to drive the same problem through different kernel forms (bitwise-reproducibility
+// tests); it is not declared in the public header include/nnop_hip.h and is not part of the ABI.
+//
+// -1 always means "automatic" (the launcher's own measured heuristic).
+#pragma once
+
+namespace nnop {
+
+enum TuneKey {
+    kTuneFwdSplit = 0,   // NNOP_FWD_SPLIT   E<=64 plain forward: 0 = 8/4-wave form, 1 = 16-wave split-KV form
+    kTuneFwdNW,          // NNOP_FWD_NW      waves per workgroup of the 32-row-per-wave forward (4 | 8)
+    kTuneFwdW64,         // NNOP_FWD_W64     64-row-per-wave forward (fa_fwd_w64.hpp): 0 = never, 1 = wherever instantiated
+    kTuneBwdBig7,        // NNOP_BWD_BIG7    workgroups from which the 7-wave E=128 backward form is used
+    kTuneNormBwdCap,     // NNOP_NORM_BWD_CAP partial rows of the norm pullbacks
+    kTuneBwdForm,        // NNOP_BWD_FORM    0 = two-kernel (7 products, no atomics), 1 = one sweep with f32 atomics for dQ
+    kTuneCount
+};
+
+// Current value of a knob (-1 = automatic).
+int tune_get(int key);
+
+}  // namespace nnop

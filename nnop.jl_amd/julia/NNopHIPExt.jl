@@ -18,8 +18,15 @@
 #
 # Install (see INTEGRATION.md):  in NNop's Project.toml
 #     [extensions]
-#     NNopHIPExt = "AMDGPU"          # replaces / sits beside NNopAMDGPUExt
+#     NNopHIPExt = "AMDGPU"          # REPLACES the line `NNopAMDGPUExt = "AMDGPU"`
 # and put this file at ext/NNopHIPExt.jl; point ENV["NNOP_HIP_LIB"] at libnnop_hip.so.
+# It replaces NNopAMDGPUExt, it cannot sit beside it: both define NNop._shared_memory(::ROCBackend, ::Integer), and
+# two extensions defining one method is a method overwrite, which Julia rejects during precompilation.
+#
+# GC / stream safety of the ccalls: every array whose raw device pointer is passed is held by GC.@preserve for the
+# duration of the call; the library only ENQUEUES kernels on the task-local HIP stream and keeps no pointer.  Arrays
+# that die right after the call (the backward workspace `ws`) are safe because AMDGPU.jl frees device memory in stream
+# order (hipFreeAsync on the same task-local stream), i.e. after the kernels enqueued here.
 module NNopHIPExt
 
 using AMDGPU
@@ -37,8 +44,13 @@ end
 # nnop_dtype
 nnop_dtype(::Type{Float32}) = Int32(0)
 nnop_dtype(::Type{Float16}) = Int32(1)
-nnop_dtype(::Type{Core.BFloat16}) = Int32(2)          # Julia >= 1.11; BFloat16s.BFloat16 has the same bits
-const HipFloat = Union{Float32, Float16, Core.BFloat16}
+# BFloat16 is a Core type from Julia 1.11 on; on older Julia the extension still loads, without the bf16 methods
+@static if isdefined(Core, :BFloat16)
+    nnop_dtype(::Type{Core.BFloat16}) = Int32(2)      # BFloat16s.BFloat16 (>= 0.5 on 1.11) is this same type
+    const HipFloat = Union{Float32, Float16, Core.BFloat16}
+else
+    const HipFloat = Union{Float32, Float16}
+end
 
 # nnop_status -> the reference's ErrorException messages (src/attention.jl:141-144, :204)
 function check(st::Cint, q, k, v)
@@ -78,7 +90,7 @@ function NNop._flash_attention(
     o  = similar(q)                                            # :166
     ms = ROCArray{T}(undef, size(q, 2), size(q, 3), size(q, 4))  # :167  (QL, QH, B)
     ls = similar(ms)                                           # :168
-    st = ccall((:nnop_fa_fwd, libnnop()), Cint,
+    st = GC.@preserve o ms ls q k v pair kpad_mask ccall((:nnop_fa_fwd, libnnop()), Cint,
         (Ptr{FaDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
         d, devptr(o), devptr(ms), devptr(ls), devptr(q), devptr(k), devptr(v), devptr(pair), devptr(kpad_mask), hipstream())
     check(st, q, k, v)
@@ -95,16 +107,23 @@ function NNop.∇flash_attention(
 ) where T <: HipFloat
     d = Ref(desc(q, k, v, causal))
     nbytes = ccall((:nnop_fa_bwd_workspace_bytes, libnnop()), Csize_t, (Ptr{FaDesc},), d)
-    if nbytes == 0                                             # invalid descriptor: fetch the status
+    if nbytes == 0
+        # invalid descriptor (the same four checks as the forward, src/attention_bwd.jl:210-213): a call with NULL
+        # tensors returns the status of the failed check before it looks at any pointer
+        null = Ptr{Cvoid}(0)
         st = ccall((:nnop_fa_bwd, libnnop()), Cint,
-            (Ptr{FaDesc}, ntuple(_ -> Ptr{Cvoid}, 14)..., Csize_t, Ptr{Cvoid}),
-            d, ntuple(_ -> Ptr{Cvoid}(0), 14)..., 0, Ptr{Cvoid}(0))
+            (Ptr{FaDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+             Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+             Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+             Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+            d, null, null, null, null, null, null, null, null, null, null, null, null, null, null, Csize_t(0), null)
         check(st, q, k, v)
+        error("libnnop_hip: invalid attention descriptor")    # unreachable when check() raised
     end
     dq, dk, dv = similar(q), similar(k), similar(v)           # fully overwritten by the library
     dp = isnothing(pair) ? nothing : similar(pair)
     ws = ROCArray{UInt8}(undef, nbytes)                        # replaces Δ_scaled / δ (:224-225)
-    st = ccall((:nnop_fa_bwd, libnnop()), Cint,
+    st = GC.@preserve dq dk dv dp Δ o ms ls q k v pair kpad_mask ws ccall((:nnop_fa_bwd, libnnop()), Cint,
         (Ptr{FaDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},          # dq dk dv dpair
          Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},                      # Δ o ms ls
          Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},          # q k v pair kpad_mask
@@ -113,6 +132,22 @@ function NNop.∇flash_attention(
         devptr(q), devptr(k), devptr(v), devptr(pair), devptr(kpad_mask), devptr(ws), nbytes, hipstream())
     check(st, q, k, v)
     return dq, dk, dv, dp
+end
+
+# A cotangent that is not a ROCArray -- the lazy `FillArrays.Fill` Zygote produces for `sum(flash_attention(...))`
+# (test/attention_tests.jl:36-41), a Broadcasted, a host Array -- would miss the method above and fall through to the
+# reference's generic KernelAbstractions backward.  Materialise it on the device and stay on the HIP path.
+_to_roc(Δ::ROCArray, like) = Δ
+_to_roc(Δ::Array, like) = copyto!(similar(like), Δ)
+_to_roc(Δ, like) = (d = similar(like); d .= Δ; d)           # Fill / lazy wrappers broadcast without scalar indexing
+function NNop.∇flash_attention(
+    Δ::AbstractArray{<:Real,4},
+    o::ROCArray{T,4}, ms::ROCArray{T,3}, ls::ROCArray{T,3},
+    q::ROCArray{T,4}, k::ROCArray{T,4}, v::ROCArray{T,4},
+    pair::Union{Nothing,ROCArray{T,4}} = nothing;
+    causal::Bool, kpad_mask::Union{Nothing,ROCMatrix{Bool}} = nothing,
+) where T <: HipFloat
+    return NNop.∇flash_attention(_to_roc(Δ, o)::ROCArray{T,4}, o, ms, ls, q, k, v, pair; causal, kpad_mask)
 end
 
 # struct nnop_rope_desc (include/nnop_hip.h)
@@ -131,7 +166,7 @@ function NNop._llama_rope(
     @assert size(cos) == size(sin) == (head_dim, q_seq, batch)
     d = Ref(RopeDesc(nnop_dtype(T), nnop_dtype(C), head_dim, q_seq, q_heads, size(k, 3), batch))
     qo, ko = similar(q), similar(k)
-    st = ccall((:nnop_llama_rope, libnnop()), Cint,
+    st = GC.@preserve qo ko q k cos sin ccall((:nnop_llama_rope, libnnop()), Cint,
         (Ptr{RopeDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}),
         d, devptr(qo), devptr(ko), devptr(q), devptr(k), devptr(cos), devptr(sin), bwd ? -1f0 : 1f0, hipstream())
     st == 0 || error("libnnop_hip: " * unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st)))
@@ -147,7 +182,7 @@ end
 function NNop.online_softmax(x::ROCMatrix{T}) where T <: HipFloat
     y = similar(x)
     d = Ref(SoftmaxDesc(nnop_dtype(T), size(x, 1), size(x, 2)))
-    st = ccall((:nnop_online_softmax, libnnop()), Cint, (Ptr{SoftmaxDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+    st = GC.@preserve y x ccall((:nnop_online_softmax, libnnop()), Cint, (Ptr{SoftmaxDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
         d, devptr(y), devptr(x), hipstream())
     st == 0 || error("libnnop_hip: " * unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st)))
     return y
@@ -159,7 +194,7 @@ function NNop.∇online_softmax(Δ::ROCMatrix{T}, y::ROCMatrix{T}) where T <: Hi
     NNop.within_gradient(y) && return invoke(NNop.∇online_softmax, Tuple{AbstractArray, AbstractArray}, Δ, y)
     dx = similar(y)
     d = Ref(SoftmaxDesc(nnop_dtype(T), size(y, 1), size(y, 2)))
-    st = ccall((:nnop_online_softmax_bwd, libnnop()), Cint,
+    st = GC.@preserve dx Δ y ccall((:nnop_online_softmax_bwd, libnnop()), Cint,
         (Ptr{SoftmaxDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), d, devptr(dx), devptr(Δ), devptr(y), hipstream())
     st == 0 || error("libnnop_hip: " * unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st)))
     return dx
@@ -176,7 +211,7 @@ ok(st) = st == 0 || error("libnnop_hip: " * unsafe_string(ccall((:nnop_strerror,
 function NNop._rms_norm(x::ROCMatrix{T}, w::ROCVector{W}; ϵ::Float32, offset::Float32 = 0f0) where {T <: HipFloat, W <: HipFloat}
     @assert size(x, 1) == length(w)
     y = similar(x); rms = ROCArray{Float32}(undef, size(x, 2))
-    ok(ccall((:nnop_rms_norm, libnnop()), Cint,
+    ok(GC.@preserve y rms x w ccall((:nnop_rms_norm, libnnop()), Cint,
         (Ptr{NormDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Cfloat, Ptr{Cvoid}),
         normdesc(x, w), devptr(y), devptr(rms), devptr(x), devptr(w), offset, ϵ, hipstream()))
     return y, rms
@@ -189,7 +224,7 @@ function NNop.∇rms_norm(Δ::ROCMatrix{T}, rms::ROCVector{Float32}, x::ROCMatri
     dx = similar(x); dw = ROCArray{Float32}(undef, size(x, 1))
     nbytes = ccall((:nnop_norm_bwd_workspace_bytes, libnnop()), Csize_t, (Ptr{NormDesc}, Cint), d, 0)
     ws = ROCArray{UInt8}(undef, nbytes)
-    ok(ccall((:nnop_rms_norm_bwd, libnnop()), Cint,
+    ok(GC.@preserve dx dw Δ rms x w ws ccall((:nnop_rms_norm_bwd, libnnop()), Cint,
         (Ptr{NormDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
         d, devptr(dx), devptr(dw), devptr(Δ), devptr(rms), devptr(x), devptr(w), offset, devptr(ws), nbytes, hipstream()))
     return dx, dw
@@ -198,7 +233,7 @@ end
 # src/layer_norm.jl:150-170
 function NNop._layer_norm(x::ROCMatrix{T}, w::ROCVector{W}, b::ROCVector{W}; ϵ::Float32 = 1f-6) where {T <: HipFloat, W <: HipFloat}
     y = similar(x); μ = ROCArray{Float32}(undef, size(x, 2)); Σ = similar(μ)
-    ok(ccall((:nnop_layer_norm, libnnop()), Cint,
+    ok(GC.@preserve y μ Σ x w b ccall((:nnop_layer_norm, libnnop()), Cint,
         (Ptr{NormDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Ptr{Cvoid}),
         normdesc(x, w), devptr(y), devptr(μ), devptr(Σ), devptr(x), devptr(w), devptr(b), ϵ, hipstream()))
     return y, μ, Σ
@@ -211,7 +246,7 @@ function NNop.∇layer_norm(Δ::ROCMatrix{T}, μ::ROCVector{Float32}, Σ::ROCVec
     dx = similar(x); dw = similar(w); db = similar(b)
     nbytes = ccall((:nnop_norm_bwd_workspace_bytes, libnnop()), Csize_t, (Ptr{NormDesc}, Cint), d, 1)
     ws = ROCArray{UInt8}(undef, nbytes)
-    ok(ccall((:nnop_layer_norm_bwd, libnnop()), Cint,
+    ok(GC.@preserve dx dw db Δ μ Σ x w ws ccall((:nnop_layer_norm_bwd, libnnop()), Cint,
         (Ptr{NormDesc}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
         d, devptr(dx), devptr(dw), devptr(db), devptr(Δ), devptr(μ), devptr(Σ), devptr(x), devptr(w), devptr(ws), nbytes, hipstream()))
     return dx, dw, db

@@ -23,7 +23,7 @@ from typing import Callable, List, Optional
 import torch
 
 __all__ = ["Rect", "unit_range", "rectangles", "shard_views", "flash_attention_sharded",
-           "all_gather_units"]
+           "flash_attention_sharded_fwd_bwd", "all_gather_units"]
 
 
 @dataclass(frozen=True)
@@ -131,3 +131,25 @@ def flash_attention_sharded(q, k, v, pair=None, *, causal: bool, kpad_mask=None,
         return local
     full = all_gather_units(local, B * KH, group=group)
     return full.reshape(B, QH, QL, E)
+
+
+def flash_attention_sharded_fwd_bwd(q, k, v, dO, pair=None, *, causal: bool, kpad_mask=None,
+                                    world: int, rank: int):
+    """This rank's share of one forward + backward, without autograd: for each of the rank's rectangles
+    ``_flash_attention`` then ``grad_flash_attention`` on the rectangle's views (pointer offsets only).
+
+    Gradients are sharded exactly like their inputs -- dq like q, dk / dv like k / v -- and need no
+    cross-rank reduction: a kv head's query heads never split across ranks (module docstring).
+    Returns a list of ``(rect, o, dq, dk, dv, dpair)`` in unit order; the tensors are the rectangle-shaped
+    results ([B', H', L, E]).  The HIP operator is the only implementation (no fallback).
+    """
+    from .attention import _flash_attention, grad_flash_attention
+    rep = q.shape[1] // k.shape[1]
+    out = []
+    for rect in rectangles(q.shape[0], k.shape[1], world, rank):
+        qs, ks, vs, ps, ms_ = shard_views(rect, q, k, v, pair, kpad_mask)
+        dos = dO[rect.b0:rect.b1, rect.kh0 * rep:rect.kh1 * rep]
+        o, m, l = _flash_attention(qs, ks, vs, ps, causal=causal, kpad_mask=ms_)
+        dq, dk, dv, dp = grad_flash_attention(dos, o, m, l, qs, ks, vs, ps, causal=causal, kpad_mask=ms_)
+        out.append((rect, o, dq, dk, dv, dp))
+    return out

@@ -31,6 +31,7 @@ import numpy as np
 __all__ = [
     "naive_attention",
     "naive_attention_grads",
+    "naive_attention_slice",
     "tiled_flash_fwd",
     "tiled_flash_bwd",
     "naive_attention_f32",
@@ -162,6 +163,61 @@ def naive_attention_grads(q, k, v, dO, pair=None, *, causal: bool, kpad_mask=Non
     if pair is not None:
         dpair = np.ascontiguousarray(np.transpose(ds, (0, 3, 2, 1)))  # [B,KL,QL,QH]
     return dq, dk, dv, dpair
+
+
+# --------------------------------------------------------------------------- one (batch, kv-head) slice
+def naive_attention_slice(q, k, v, dO=None, *, causal: bool, kpad_mask=None, chunk: int = 1024):
+    """The naive formula (test/attention_testsetup.jl:21-45) and its analytic gradients
+    (src/attention_bwd.jl:86-156, as in naive_attention_grads) for ONE (batch, kv-head) slice,
+    evaluated in fp64 over query-row chunks so that the L x L score matrix of a BASELINE-sized
+    problem (L = 8192 .. 16384) never exists at once.  Same math, same order of the masks; every
+    (batch, kv-head) slice is independent (src/attention.jl:27-28,33), so a slice of the full-size
+    launch can be checked without evaluating the rest.
+
+        q, dO : [G, QL, E]   the G = QH/KH query heads that share this kv head
+        k, v  : [KL, E]      kpad_mask : [KL] bool or None
+
+    Returns dict(o [G,QL,E], ms [G,QL], ls [G,QL]) and, when dO is given, dq [G,QL,E], dk, dv [KL,E]
+    (dk, dv summed over the G query heads, src/attention_bwd.jl:99-103,138-142).
+    """
+    q = np.asarray(q, np.float64)
+    k = np.asarray(k, np.float64)
+    v = np.asarray(v, np.float64)
+    G, QL, E = q.shape
+    KL = k.shape[0]
+    scale = 1.0 / np.sqrt(np.float64(E))
+    out = dict(o=np.empty_like(q), ms=np.empty((G, QL)), ls=np.empty((G, QL)))
+    if dO is not None:
+        dO = np.asarray(dO, np.float64)
+        out.update(dq=np.empty_like(q), dk=np.zeros_like(k), dv=np.zeros_like(v))
+    kidx = np.arange(KL)
+    valid = None if kpad_mask is None else np.asarray(kpad_mask, bool)
+    for g in range(G):
+        for q0 in range(0, QL, chunk):
+            q1 = min(q0 + chunk, QL)
+            kl = min(KL, q1) if causal else KL           # keys beyond the chunk's last row are masked anyway
+            a = (q[g, q0:q1] @ k[:kl].T) * scale
+            if causal:
+                a = np.where(kidx[None, :kl] <= np.arange(q0, q1)[:, None], a, -np.inf)
+            if valid is not None:
+                a = np.where(valid[None, :kl], a, -np.inf)
+            with np.errstate(invalid="ignore"):
+                mx = a.max(axis=1, keepdims=True)
+                t = np.exp(a - mx)
+                l = t.sum(axis=1, keepdims=True)
+                p = t / l
+            o = p @ v[:kl]
+            out["o"][g, q0:q1] = o
+            out["ms"][g, q0:q1] = mx[:, 0]
+            out["ls"][g, q0:q1] = l[:, 0]
+            if dO is not None:
+                d = dO[g, q0:q1]
+                out["dv"][:kl] += p.T @ d
+                dp = d @ v[:kl].T
+                ds = p * (dp - np.sum(d * o, axis=1, keepdims=True))
+                out["dq"][g, q0:q1] = (ds @ k[:kl]) * scale
+                out["dk"][:kl] += (ds.T @ q[g, q0:q1]) * scale
+    return out
 
 
 # --------------------------------------------------------------------------- tiled fwd

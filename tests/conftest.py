@@ -24,3 +24,19 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def tune(pkg):
+    """Override launch-shape knobs of the library for one test (csrc/nnop_debug.h) and restore them afterwards.
+    `tune(fwd_split=0, fwd_nw=4)`; -1 = automatic."""
+    saved = {}
+
+    def _set(**kw):
+        for k, v in kw.items():
+            prev = pkg._lib.debug_set(k, v)
+            saved.setdefault(k, prev)
+
+    yield _set
+    for k, v in saved.items():
+        pkg._lib.debug_set(k, v)

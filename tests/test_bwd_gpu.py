@@ -91,10 +91,10 @@ def test_rrule_through_autograd(pkg, dev, dt):
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("causal", [False, True])
-def test_e128_seven_wave_backward_form(pkg, dev, dt, causal, monkeypatch):
+def test_e128_seven_wave_backward_form(pkg, dev, dt, causal, tune):
     """E = 128 backward has two workgroup shapes (4 waves / 7 waves with single-buffered tiles, chosen by grid
     size).  Force each and check both against the oracle; 224-row blocks exercise ragged block tails."""
     d = make_inputs(17, 2, 4, 2, 700, 700, 128, dt, dev, pad="ref" if causal else None)
-    for thr in ("1", "100000000"):
-        monkeypatch.setenv("NNOP_BWD_BIG7", thr)
+    for thr in (1, 100000000):
+        tune(bwd_big7=thr)
         check_bwd(pkg, d, causal, dt)

@@ -98,3 +98,13 @@ def test_workmodel_matches_the_oracles_work_model(pkg):
     for bwd in (False, True):
         assert wm.softmax_bytes(1024, 7, 4, bwd=bwd) == softmax_bytes(1024, 7, 4, bwd=bwd)
         assert wm.norm_bytes(1024, 7, 2, bwd=bwd) == norm_bytes(1024, 7, 2, bwd=bwd)
+
+
+def test_rectangles_cover_every_unit_once(pkg):
+    for B, KH in ((4, 4), (64, 32), (1, 3), (5, 7)):
+        for world in (1, 2, 3, 8):
+            got = []
+            for rank in range(world):
+                for r in pkg.shard.rectangles(B, KH, world, rank):
+                    got += [b * KH + kh for b in range(r.b0, r.b1) for kh in range(r.kh0, r.kh1)]
+            assert got == list(range(B * KH))

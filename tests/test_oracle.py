@@ -166,3 +166,22 @@ def test_work_model_matches_survey_numbers():
     assert attention_bytes(64, 4096, 4096, 4, 4, 4, 4) == 67_633_152
     assert attention_bytes(128, 8192, 8192, 32, 32, 8, 2) == 2_155_872_256
     assert attention_bytes(128, 8192, 8192, 32, 32, 8, 2, mode="bwd") == 4_303_355_904
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_slice_oracle_equals_full_oracle(causal):
+    """naive_attention_slice (query-row chunks, used at the full BASELINE shapes) is the same formula as
+    naive_attention / naive_attention_grads restricted to one (batch, kv-head) slice."""
+    from oracle.naive_attention import naive_attention_slice
+    rng = np.random.default_rng(5)
+    B, QH, KH, L, E = 2, 4, 2, 300, 32
+    q, do = rng.standard_normal((B, QH, L, E)), rng.standard_normal((B, QH, L, E))
+    k, v = rng.standard_normal((B, KH, L, E)), rng.standard_normal((B, KH, L, E))
+    m = np.ones((B, L), bool)
+    m[1, -40:] = False
+    o, ms, ls = naive_attention(q, k, v, causal=causal, kpad_mask=m, return_stats=True)
+    dq, dk, dv, _ = naive_attention_grads(q, k, v, do, causal=causal, kpad_mask=m)
+    r = naive_attention_slice(q[1, 2:4], k[1, 1], v[1, 1], do[1, 2:4], causal=causal, kpad_mask=m[1], chunk=64)
+    for got, ref in ((r["o"], o[1, 2:4]), (r["ms"], ms[1, 2:4]), (r["ls"], ls[1, 2:4]), (r["dq"], dq[1, 2:4]),
+                     (r["dk"], dk[1, 1]), (r["dv"], dv[1, 1])):
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-11)

@@ -1,0 +1,121 @@
+"""The reference's three attention test grids, VERBATIM, on the HIP path (through the C ABI and the rrule mirror):
+
+  test/attention_tests.jl:6-48         padmask x pair x E{16,32,64} x QL{255,256,511,512,1024} x KL{same}, H=2, B=3   (300)
+  test/causal_attention_tests.jl:6-46  padmask x pair x E{16,32,64} x L{255,256,511,512,1024}, causal, H=2, B=3        (60)
+  test/gqa_attention_tests.jl:6-33     QH{4,6,8} x KVH{1,2} x causal x E{32,64} x L{255,256,257,512}, B=2              (96)
+
+Same shapes, same key-padding pattern (last 11 keys of the last batch), same objective: `sum(flash_attention(...))`
+differentiated w.r.t. q, k, v (and pair) -- i.e. the cotangent is all ones -- compared with the naive formula.  The
+reference runs them in Float32 only ("TODO more types"); here every case also runs in bf16 and fp16.
+
+Criteria per case:
+  * the reference's own: isapprox(sum(o1), sum(o2); atol=1e-3, rtol=1e-3) on the scalar and Julia's norm-wise array
+    isapprox(atol=1e-3, rtol=1e-3) on every gradient (`util.jl_isapprox`) -- for Float32, as in the reference;
+  * the strict element-wise check of `util.assert_close` against the fp64 oracle for all three dtypes (for the 16-bit types
+    the norm-wise criterion is applied at the north_star tolerance rtol = 1e-2).
+
+Inputs are N(0,1) rounded to bf16, so they are exact in all three dtypes and one fp64 oracle evaluation serves all three.
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.naive_attention import naive_attention, naive_attention_grads
+from util import TORCH_DT, assert_close, jl_isapprox
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = ["f32", "bf16", "f16"]
+_cache = {}
+
+
+def _bf16_exact(rng, *shape):
+    x = torch.tensor(rng.standard_normal(shape).astype(np.float32)).to(torch.bfloat16)
+    return x.to(torch.float64).numpy()
+
+
+def _case(key, B, QH, KH, QL, KL, E, causal, use_padmask, use_pair):
+    """Inputs + fp64 oracle of one grid point (cached for the three dtypes that follow each other)."""
+    if _cache.get("key") == key:
+        return _cache["val"]
+    rng = np.random.default_rng(zlib.crc32(repr(key).encode()))
+    q, k, v = _bf16_exact(rng, B, QH, QL, E), _bf16_exact(rng, B, KH, KL, E), _bf16_exact(rng, B, KH, KL, E)
+    pair = _bf16_exact(rng, B, KL, QL, QH) if use_pair else None             # Julia (H, QL, KL, B)
+    mask = None
+    if use_padmask:
+        mask = np.ones((B, KL), dtype=bool)
+        mask[-1, -11:] = False                                               # kpad_mask[end-10:end, end] .= false
+    do = np.ones((B, QH, QL, E))                                             # cotangent of sum(o)
+    o = naive_attention(q, k, v, pair, causal=causal, kpad_mask=mask)
+    grads = naive_attention_grads(q, k, v, do, pair, causal=causal, kpad_mask=mask)
+    val = dict(q=q, k=k, v=v, pair=pair, mask=mask, o=o, grads=grads)
+    _cache.update(key=key, val=val)
+    return val
+
+
+def _run(pkg, dev, dt, c, causal):
+    tdt = TORCH_DT[dt]
+    dev_t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64).to(tdt).to(dev)
+    q, k, v, pair = dev_t(c["q"]), dev_t(c["k"]), dev_t(c["v"]), dev_t(c["pair"])
+    mask = None if c["mask"] is None else torch.tensor(c["mask"]).to(dev)
+    leaves = [t.requires_grad_(True) for t in (q, k, v)] + ([pair.requires_grad_(True)] if pair is not None else [])
+    o = pkg.flash_attention(q, k, v, pair, causal=causal, kpad_mask=mask)
+    # Zygote.withgradient(...) do sum(NNop.flash_attention(...)) end
+    total = o.double().sum()
+    total.backward()
+    torch.cuda.synchronize()
+    names = ["dq", "dk", "dv"] + (["dpair"] if pair is not None else [])
+    # the reference's criteria (Float32 grid) / the same norm-wise criterion at the 16-bit tolerance
+    tol = 1e-3 if dt == "f32" else 1e-2
+    s_ref, s_got = float(c["o"].sum()), float(total)
+    # Float32: exactly the reference's scalar isapprox.  16-bit: the sum of ~4e5 independently rounded outputs is compared
+    # on the scale of ||o||_2 (a 1 % systematic bias would still fail), the scalar itself is a cancelling sum
+    s_scale = max(abs(s_ref), abs(s_got)) if dt == "f32" else max(abs(s_ref), float(np.linalg.norm(c["o"])))
+    assert abs(s_ref - s_got) <= max(tol, tol * s_scale), f"sum(o): {s_got} vs {s_ref}"
+    for name, leaf, ref in zip(names, leaves, c["grads"]):
+        g = leaf.grad.double().cpu().numpy()
+        assert jl_isapprox(g, ref, atol=tol, rtol=tol), f"{name}: norm-wise isapprox({tol}) failed"
+    # strict element-wise
+    assert_close("o", o, c["o"], dt)
+    for name, leaf, ref in zip(names, leaves, c["grads"]):
+        assert_close(name, leaf.grad, ref, dt, kind="grad")
+
+
+# test/attention_tests.jl:6-20  (dt on top = varies fastest, so the oracle cache of a grid point serves its three dtypes)
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("use_padmask", [False, True])
+@pytest.mark.parametrize("use_pair", [False, True])
+@pytest.mark.parametrize("E", [16, 32, 64])
+@pytest.mark.parametrize("QL", [255, 256, 511, 512, 1024])
+@pytest.mark.parametrize("KL", [255, 256, 511, 512, 1024])
+def test_flash_attention_grid(pkg, dev, dt, KL, QL, E, use_pair, use_padmask):
+    H, B = 2, 3
+    c = _case(("att", use_padmask, use_pair, E, QL, KL), B, H, H, QL, KL, E, False, use_padmask, use_pair)
+    _run(pkg, dev, dt, c, False)
+
+
+# test/causal_attention_tests.jl:6-18
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("use_padmask", [False, True])
+@pytest.mark.parametrize("use_pair", [False, True])
+@pytest.mark.parametrize("E", [16, 32, 64])
+@pytest.mark.parametrize("L", [255, 256, 511, 512, 1024])
+def test_causal_flash_attention_grid(pkg, dev, dt, L, E, use_pair, use_padmask):
+    H, B = 2, 3
+    c = _case(("causal", use_padmask, use_pair, E, L), B, H, H, L, L, E, True, use_padmask, use_pair)
+    _run(pkg, dev, dt, c, True)
+
+
+# test/gqa_attention_tests.jl:6-19
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("QH", [4, 6, 8])
+@pytest.mark.parametrize("KVH", [1, 2])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("E", [32, 64])
+@pytest.mark.parametrize("L", [255, 256, 257, 512])
+def test_grouped_query_attention_grid(pkg, dev, dt, L, E, causal, KVH, QH):
+    B = 2
+    c = _case(("gqa", QH, KVH, causal, E, L), B, QH, KVH, L, L, E, causal, False, False)
+    _run(pkg, dev, dt, c, causal)

@@ -160,3 +160,33 @@ def test_rope_golden(pkg, path, dt):
     dq, dk = pkg.grad_llama_rope((t("dq_out"), t("dk_out")), cos, sin)
     for got, name in ((qo, "q_out"), (ko, "k_out"), (dq, "dq"), (dk, "dk")):
         _check(got, g[name].astype(np.float64), dt)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("which", ["q", "cos", "out"])
+def test_offset_views_take_the_elementwise_kernel(pkg, dt, which):
+    """A C / Julia caller may hand over a view that starts 4 or 8 bytes into an allocation: dense, but not 16-byte aligned.
+    The launcher must not issue its 16-byte vector accesses there (csrc/rope.hip picks the element-wise kernel); results
+    are the same as from aligned storage."""
+    B, QH, KH, L, D = 2, 3, 2, 130, 64
+    q, k, cos, sin = _mk(77, B, QH, KH, L, D, dt)
+    ref_q, ref_k = pkg.llama_rope_into(torch.empty_like(q), torch.empty_like(k), q, k, cos, sin)
+
+    def misaligned_like(t):
+        flat = torch.empty(t.numel() + 2, dtype=t.dtype, device=t.device)
+        view = flat[1:1 + t.numel()].view(t.shape)                  # one element (2 or 4 bytes) past a 16-byte boundary
+        assert view.data_ptr() % 16 != 0 and view.is_contiguous()
+        view.copy_(t)
+        return view
+
+    q_in, cos_in, sin_in = q, cos, sin
+    q_out = torch.empty_like(q)
+    if which == "q":
+        q_in = misaligned_like(q)
+    elif which == "cos":
+        cos_in, sin_in = misaligned_like(cos), misaligned_like(sin)
+    else:
+        q_out = misaligned_like(q)
+    got_q, got_k = pkg.llama_rope_into(q_out, torch.empty_like(k), q_in, k, cos_in, sin_in)
+    torch.cuda.synchronize()
+    assert torch.equal(got_q, ref_q) and torch.equal(got_k, ref_k)

@@ -1,4 +1,7 @@
 """Shared helpers for the parity tests (test infrastructure)."""
+import json
+import os
+
 import numpy as np
 import torch
 
@@ -10,6 +13,7 @@ TORCH_DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 # tensor's max magnitude.
 RTOL = {"f32": 1e-4, "f16": 1e-2, "bf16": 1e-2}
 ATOL_FRAC = {"f32": 1e-5, "f16": 2e-3, "bf16": 1e-2}
+GRAD_SCALE = {"f32": 1.0, "f16": 2.0, "bf16": 2.0}
 
 
 def make_inputs(seed, B, QH, KH, QL, KL, E, dt, dev, *, pair=False, pad=None, need_do=True):
@@ -56,9 +60,21 @@ def oracle_bwd(d, causal):
 ABS_FLOOR = {"f32": 1e-5, "f16": 1e-2, "bf16": 6e-2}
 
 
-def assert_close(name, got, ref, dt, scale=1.0, floor=False):
+def record_error(kind, rec):
+    """Calibration aid: with NNOP_TEST_ERRLOG=<file> every comparison appends its measured error (one JSON line), which
+    is where the 16-bit tolerances above come from (profiles/r02/parity_errors.json)."""
+    path = os.environ.get("NNOP_TEST_ERRLOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(kind=kind, **rec)) + "\n")
+
+
+def assert_close(name, got, ref, dt, scale=1.0, floor=False, kind="fwd"):
     """|got - ref| <= atol + rtol*|ref| element-wise, atol = ATOL_FRAC * max|ref|; plus the
-    reference's own norm-wise check (isapprox atol=rtol=1e-3, test/attention_tests.jl:42-48) for f32."""
+    reference's own norm-wise check (isapprox atol=rtol=1e-3, test/attention_tests.jl:42-48) for f32.
+    kind="grad": gradient tensors (16-bit: the residuals ms, ls they are computed from are stored in T)."""
+    if kind == "grad" and scale == 1.0:
+        scale = GRAD_SCALE[dt]
     g = to64(got) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
     assert g.shape == ref.shape, f"{name}: shape {g.shape} vs {ref.shape}"
     both_nan = np.isnan(g) & np.isnan(ref)
@@ -68,6 +84,9 @@ def assert_close(name, got, ref, dt, scale=1.0, floor=False):
     tol = scale * (ATOL_FRAC[dt] * mag + RTOL[dt] * np.abs(rz)) + (ABS_FLOOR[dt] if floor else 0.0)
     err = np.abs(gz - rz)
     bad = err > tol
+    record_error("assert_close", dict(name=name.split(" ")[-1], dt=dt, rel_to_max=float(err.max() / max(mag, 1e-30)) if err.size else 0.0,
+                                      worst_ratio=float((err / np.maximum(tol, 1e-300)).max()) if err.size else 0.0,
+                                      scale=scale, floor=bool(floor)))
     assert not bad.any(), (f"{name} [{dt}]: {bad.sum()} / {bad.size} outside tolerance; "
                            f"max err {err.max():.3e} (max|ref| {mag:.3e})")
     if dt == "f32" and not floor:

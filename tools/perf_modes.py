@@ -1,4 +1,4 @@
-"""dev: per-tile cost of the forward's modes on the SAME non-causal problem: plain split-KV, plain 8-wave (NNOP_FWD_SPLIT=0),
+"""dev: per-tile cost of the forward's modes on the SAME non-causal problem: plain split-KV, plain 8-wave (knob fwd_split=0),
 masked mode via an all-valid key-padding mask; and the causal run of the same shape.  usage: perf_modes.py [dt:E:L:H:B ...]"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,6 +6,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 pkg = ge.load_package()
 dev = torch.device("cuda:0")
+T = pkg._lib.debug_set          # launch-shape knobs (csrc/tuning.hpp); -1 = automatic
+T("fwd_w64", 0)
 DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 def timeit(f, n=30):
     for _ in range(3): f()
@@ -21,11 +23,11 @@ for c in sys.argv[1:] or ["bf16:64:4096:16:4", "bf16:128:4096:16:4"]:
     o = torch.empty_like(q); ms = torch.empty(B, H, L, dtype=DT[dt], device=dev); ls = torch.empty_like(ms)
     mask = torch.ones(B, L, dtype=torch.bool, device=dev)
     res = {}
-    os.environ["NNOP_FWD_SPLIT"] = "1"; res["plain split"] = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=False))
-    os.environ["NNOP_FWD_SPLIT"] = "0"; res["plain 8w"] = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=False))
-    os.environ["NNOP_FWD_NW"] = "4"; res["plain 4w"] = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=False)); del os.environ["NNOP_FWD_NW"]
-    os.environ["NNOP_FWD_SPLIT"] = "1"
+    T("fwd_split", 1); res["plain split"] = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=False))
+    T("fwd_split", 0); res["plain 8w"] = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=False))
+    T("fwd_nw", 4); res["plain 4w"] = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=False)); T("fwd_nw", -1)
+    T("fwd_split", 1)
     res["masked(all valid) 8w"] = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=False, kpad_mask=mask))
-    os.environ["NNOP_FWD_NW"] = "4"; res["masked(all valid) 4w"] = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=False, kpad_mask=mask)); del os.environ["NNOP_FWD_NW"]
+    T("fwd_nw", 4); res["masked(all valid) 4w"] = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=False, kpad_mask=mask)); T("fwd_nw", -1)
     res["causal (default)"] = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=True))
     print(c, " | ".join(f"{k_} {v_:.1f}" for k_, v_ in res.items()), flush=True)

@@ -17,7 +17,7 @@ for dt in (torch.bfloat16, torch.float16):
                       ("ones*0.1", lambda: torch.full((B, H, L, E), 0.1, device=dev)), ("randn*0.01", lambda: 0.01 * torch.randn(B, H, L, E, device=dev))]:
         q, k, v = (gen().to(dt) for _ in range(3))
         o = torch.empty_like(q); ms = torch.empty(B, H, L, dtype=dt, device=dev); ls = torch.empty_like(ms)
-        for sp in ("0", "1"):
-            os.environ["NNOP_FWD_SPLIT"] = sp
+        for sp in (0, 1):
+            pkg._lib.debug_set("fwd_split", sp)
             t = timeit(lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=False))
             print(f"{str(dt)[6:]:9s} {name:11s} split={sp}: {t:7.1f} us  {68719.476736 / t:7.1f} TF", flush=True)
