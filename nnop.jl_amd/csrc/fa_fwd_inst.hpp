@@ -8,6 +8,7 @@
 #pragma once
 #include "fa_fwd.hpp"
 #include "fa_fwd_split.hpp"
+#include "fa_fwd_w64.hpp"
 #ifdef NNOP_DEV_BUILD
 #include "fa_fwd_split16.hpp"      // measured 7 % slower than the 32x32x16 body: experiments only (make DEV=1)
 #include <stdlib.h>
@@ -91,6 +92,28 @@ static int launch_fwd_split(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
+// 64-rows-per-wave form (fa_fwd_w64.hpp): 4 waves x 64 rows, 16-bit types, E = 64 / 128, plain and masked modes
+template <typename T, int E, int MODE>
+static int launch_fwd_w64(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+    constexpr int lds = fa_fwd_w64_lds_bytes<T, E>(MODE != 0);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fa_fwd_w64_kernel<T, E, MODE>;
+    static unsigned long long lds_done = 0;
+    if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
+    FwdParams p;
+    p.o = a.o; p.ms = a.ms; p.ls = a.ls;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.pair = nullptr; p.kpad = a.kpad;
+    p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
+    p.causal = d.causal ? 1 : 0;
+    p.n_qblk = (d.ql + 255) / 256;
+    const long long n_wg = (long long)p.n_qblk * d.qh * d.batch;
+    if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    p.n_wg = (int)n_wg;
+    p.scale = (float)(1.0 / sqrt((double)E));
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds, s, p);
+    return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
+}
+
 template <typename T, int E, int NW, int QB>
 static int launch_fwd_mode(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s, int mode) {
     if (mode == 0) return launch_fwd_cfg<T, E, NW, 0, QB>(d, a, s);
@@ -105,6 +128,14 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     // Workgroup shape: 8 waves x 32 rows (256-row workgroups) when that still yields >= one
     // workgroup per CU, else 4 waves x 32 rows so that small problems spread over more CUs.
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
+    if constexpr (sizeof(T) == 2 && (E == 64 || E == 128)) {
+        // 64-row waves (fa_fwd_w64.hpp).  Knob kTuneFwdW64: 0 never, 1 wherever instantiated, auto = measured choice
+        const int w64 = tune_get(kTuneFwdW64);
+        if (mode != 2 && w64 == 1) {
+            if (mode == 0) return launch_fwd_w64<T, E, 0>(d, a, s);
+            return launch_fwd_w64<T, E, 1>(d, a, s);
+        }
+    }
     if constexpr (sizeof(T) == 2 && E <= 64) {
         // default for plain mode: 16-wave split-KV workgroups (4 waves per SIMD); measured 5-13 % faster than
         // the 8-wave form from 64 to 4096 workgroups.  Knob kTuneFwdSplit: 0 off, 1 / auto on;

@@ -1,0 +1,604 @@
+// fa_fwd_w64.hpp -- forward kernel, "64 query rows per wave, one wave per SIMD" form (16-bit types, E = 64 / 128).
+//
+// What `_flash_attention_fwd!` computes (src/attention.jl:1-131), third program form next to fa_fwd.hpp (32 rows per
+// wave, 2 waves per SIMD) and fa_fwd_split.hpp (32 rows per wave, 4 waves per SIMD).  The structure is the one the CDNA4
+// guide measures fastest for attention on this part: a workgroup = 4 waves = 256 query rows, each wave owns 64 rows (two
+// 32-row blocks z = 0, 1) and the WHOLE register file of its SIMD (512 registers per lane):
+//
+//   * O^T accumulators (2 x E/32 tiles = 128 registers at E = 128) and the Q fragments (64) live in the ACCUMULATOR
+//     file; the arch VGPRs hold two score tiles (this kv tile's and the next one's), K / V fragments and the softmax
+//     temporaries.  hipcc cannot be made to split the files that way with MFMA builtins (it moves score tiles through
+//     AGPRs: ~440 v_accvgpr moves per kv tile, measured 1.3x slower -- DESIGN.md section 5), so every MFMA here is
+//     inline asm with explicit register classes ("a" = accumulator file): the compiler only allocates.
+//   * every K / V fragment read from LDS feeds TWO MFMAs (z = 0, 1): half the LDS bytes per FLOP of the 32-row forms.
+//   * K / V tiles arrive by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no staging registers, no
+//     ds_write): the LDS images are the same swizzled RowImg / blocked ColImg as everywhere else, the swizzle is applied
+//     to each lane's SOURCE address (the DMA destination is lane-linear); rings of 3 slots, loads issued two tiles
+//     ahead right after the tile's barrier, retired by a counted wait before the next barrier (raw s_barrier: the
+//     DMA stays in flight across everything else).
+//   * one barrier per kv tile.  The loop body is software-pipelined across tiles and HAND-PLACED: it is a sequence of
+//     "slots" -- one MFMA, the LDS fragment read three fragments ahead, and a fixed share of the other tile's softmax
+//     VALU work (phase X: QK^T of tile t+1 beside exp / sum / convert of tile t; phase Y: PV of tile t beside the rest
+//     of the softmax and the row max of tile t+1) -- each closed by sched_barrier(0), because hipcc does not interleave
+//     inline-asm MFMAs with VALU work on its own (it models an asm statement as a 1-cycle instruction).
+//   * wait states the compiler would pad around a builtin MFMA are explicit (hipcc pads nothing around asm):
+//     MFMA result -> VALU read (fence_mfma_result), VALU result -> MFMA operand (fence_valu_operand).
+//
+// Modes: 0 plain (KL % 64 == 0, every logit live) / 1 masked (causal, key padding, ragged KL); the pair-bias mode stays
+// on fa_fwd.hpp.  Same numerics contract as the other forms (fp32 softmax, deferred row max with threshold 2^8, O
+// normalised once in the epilogue, residuals ms / ls per src/attention.jl:128-129).
+#pragma once
+#include <utility>
+#include "fa_fwd.hpp"
+
+// timing-only ablations of the hand-placed loop (make DEV=1 VAR=-DNNOP_W64_ABL=n; results WRONG by construction):
+//   1 no LDS-DMA in the loop   2 no tile barrier   3 no softmax arithmetic   4 no row max   5 no LDS fragment reads
+#if !defined(NNOP_DEV_BUILD)
+#undef NNOP_W64_ABL
+#endif
+#ifndef NNOP_W64_ABL
+#define NNOP_W64_ABL 0
+#endif
+#ifndef NNOP_W64_PF64
+#define NNOP_W64_PF64 3
+#endif
+#ifndef NNOP_W64_PF128
+#define NNOP_W64_PF128 3
+#endif
+
+namespace nnop {
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  The hand-placed loop body must not
+// depend on the unroller (its size estimate of a body full of `if (i == ...)` blocks exceeds the pragma threshold and the
+// loop then stays rolled, with every register array indexed at run time).
+template <int... I, typename F> NNOP_DEV void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> NNOP_DEV void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// ---- inline-asm MFMAs with explicit register files ------------------------------------------------------------------
+template <typename T> struct MfmaAsm;
+#define NNOP_MFMA_ASM(TYPE, FRAG, MNEMONIC)                                                                     \
+    template <> struct MfmaAsm<TYPE> {                                                                          \
+        /* D(vgpr) = A(vgpr) x B(acc file) */                                                                   \
+        static NNOP_DEV f32x16 qk_first(FRAG a, FRAG bq) {                                                      \
+            f32x16 d;                                                                                           \
+            asm(MNEMONIC " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(bq));                                        \
+            return d;                                                                                           \
+        }                                                                                                       \
+        static NNOP_DEV void qk_acc(f32x16& d, FRAG a, FRAG bq) {                                               \
+            asm(MNEMONIC " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(bq));                                        \
+        }                                                                                                       \
+        /* O(acc file) += A(vgpr) x B(vgpr) */                                                                  \
+        static NNOP_DEV void pv_acc(f32x16& o, FRAG a, FRAG b) {                                                \
+            asm(MNEMONIC " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                         \
+        }                                                                                                       \
+    };
+NNOP_MFMA_ASM(__bf16, bf16x8, "v_mfma_f32_32x32x16_bf16")
+NNOP_MFMA_ASM(_Float16, f16x8, "v_mfma_f32_32x32x16_f16")
+#undef NNOP_MFMA_ASM
+
+// MFMA result (8-pass) -> first non-MFMA reader: 12 wait states that hipcc does not insert after an asm MFMA.  The data
+// dependence through the operands keeps every reader below the statement.
+NNOP_DEV void fence_mfma_result(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
+    asm volatile("s_nop 11" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+NNOP_DEV void fence_acc_result(f32x16& a) { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(a)); }
+// VALU-written registers -> MFMA A/B operand inside an asm statement: 2 wait states
+template <typename F> NNOP_DEV void fence_valu_operand(F& a, F& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
+
+// Q fragment: 16 bytes per lane straight from HBM into the accumulator file (an MFMA B operand may be an AGPR).  The
+// load is invisible to hipcc's wait-count bookkeeping: the destination is valid only after the `s_waitcnt vmcnt(0)` of
+// q_landed(), which takes the fragments as operands so that no consumer can be scheduled above it.
+template <typename F> NNOP_DEV F load_q_frag(const void* gptr) {
+    F d;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(d) : "v"(gptr) : "memory");
+    return d;
+}
+
+// one 1-KiB LDS-DMA piece: lane l copies 16 bytes from (sbase + voff) to LDS byte (lds_dst + 16 l); lds_dst wave-uniform.
+// M0 (the DMA's LDS base) is written in the same statement that uses it and restored (the compiler owns M0).
+NNOP_DEV void dma_piece(const char* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// same, every lane with its own 64-bit source address (ragged tiles: rows clamped into the tensor)
+NNOP_DEV void dma_piece_addr(const char* vaddr, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vaddr), "s"(lds_dst) : "memory");
+}
+
+template <typename T, int E> constexpr int fa_fwd_w64_lds_bytes(bool masked) {
+    return 3 * (RowImg<T, E>::bytes(64) + ColImg<T, E>::bytes(64)) + (masked ? 16 + 8 * kMaxMaskTiles : 0);
+}
+
+template <typename T, int E, int MODE>
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
+    static_assert(sizeof(T) == 2 && (E == 64 || E == 128), "16-bit element types, E = 64 or 128");
+    using frag_t = typename Elem<T>::frag;
+    using KImg   = RowImg<T, E>;
+    using VImg   = ColImg<T, E>;
+    using MM     = MfmaAsm<T>;
+    constexpr bool kGeneral = MODE != 0;
+    constexpr int BK = 64, KB = 2, KS = E / 16, EB = E / 32, NS = 3;
+    constexpr int KBYTES = KImg::bytes(BK), VBYTES = VImg::bytes(BK);
+    constexpr int TILE_BYTES = BK * E * (int)sizeof(T);       // one kv tile in HBM
+    constexpr int NJ = KBYTES / 4096;                         // DMA pieces per wave per tile and tensor
+    static_assert(KBYTES == VBYTES && KBYTES % 4096 == 0, "");
+    constexpr int NKF = KB * KS;                              // K fragments per tile (each feeds z = 0, 1)
+    constexpr int NVF = 2 * KB * EB;                          // V fragments per tile
+    constexpr int NF = NKF + NVF;                             // fragment stream of one iteration
+    constexpr int NX = 2 * NKF, NY = 2 * NVF;                 // MFMA slots of phase X / phase Y
+    constexpr int PF = E >= 128 ? NNOP_W64_PF128 : NNOP_W64_PF64, RF = PF < 4 ? 4 : 8;      // fragments read ahead / fragment ring
+    static_assert(NF % RF == 0, "the fragment ring index must be static across iterations");
+    constexpr float kThr = 8.0f;
+    constexpr uint64_t kFull = ~0ull;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- which (batch, q-head, q-block) ------------------------------------------------------------------------
+    const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_qblk * (p.QH / p.KH));
+    int qblk = lin % p.n_qblk;
+    const int bh = lin / p.n_qblk;
+    if (kGeneral && p.causal) qblk = p.n_qblk - 1 - qblk;    // heaviest q-blocks first
+    const int b = bh / p.QH, qh = bh - b * p.QH;
+    const int kvh = qh / (p.QH / p.KH);                      // cld(q_head, n_q_per_kv), 0-based (src/attention.jl:28)
+    const int q0w = qblk * 256 + wave * 64;                  // first query row of this wave
+    int qi[2];
+    qi[0] = q0w + r;
+    qi[1] = q0w + 32 + r;
+
+    const T* __restrict__ qp = (const T*)p.q + ((size_t)bh * p.QL) * E;
+    const char* __restrict__ kp = (const char*)((const T*)p.k + ((size_t)(b * p.KH + kvh) * p.KL) * E);
+    const char* __restrict__ vp = (const char*)((const T*)p.v + ((size_t)(b * p.KH + kvh) * p.KL) * E);
+    const uint8_t* __restrict__ mp = kGeneral && p.kpad ? p.kpad + (size_t)b * p.KL : nullptr;
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;         // LDS byte address of the dynamic segment
+    const uint32_t kring = lds0, vring = lds0 + NS * KBYTES;
+    uint64_t* const vbits = reinterpret_cast<uint64_t*>(smem + NS * (KBYTES + VBYTES) + 16);
+
+    // ---- number of kv tiles (workgroup) / live tiles (this wave) ------------------------------------------------
+    // Masked mode keeps ONE description of "which keys exist and are valid": a 64-bit word per kv tile in LDS (key
+    // padding: built from the mask row by kpad_scan; otherwise ones up to KL).  The loop body then has no branch on a
+    // launch-constant (causal? mask given?) -- hipcc would unswitch the whole hand-placed loop on each of them.  The
+    // launcher sends sequences beyond kMaxMaskTiles tiles to the 32-row kernel.
+    int n_tiles = (p.KL + BK - 1) / BK;
+    int causal_q0 = 0x3fffffff;                              // first query row of the wave if causal, else "never clipped"
+    int qlim[2] = {0x3fffffff, 0x3fffffff};                  // per lane: last visible key (causal: the query index)
+    if constexpr (kGeneral) {
+        if (p.causal) {
+            int q_last = qblk * 256 + 255;
+            if (q_last > p.QL - 1) q_last = p.QL - 1;
+            const int t_c = q_last / BK + 1;
+            if (t_c < n_tiles) n_tiles = t_c;
+            causal_q0 = q0w;
+            qlim[0] = qi[0];
+            qlim[1] = qi[1];
+        }
+        if (mp) {
+            int* slot = reinterpret_cast<int*>(smem + NS * (KBYTES + VBYTES));
+            const int nk = n_tiles * BK < p.KL ? n_tiles * BK : p.KL;
+            const int last = kpad_scan(mp, p.KL, nk, vbits, kMaxMaskTiles, slot, tid, 256);
+            const int t_m = last / BK + 1;
+            if (t_m < n_tiles) n_tiles = t_m;
+        } else {
+            for (int w = tid; w < n_tiles; w += 256) {
+                const int left = p.KL - w * BK;
+                vbits[w] = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            }
+            __syncthreads();
+        }
+    }
+    int n_live = n_tiles;
+    if (kGeneral && p.causal) {
+        const int t_w = (q0w + 63) / BK + 1;
+        if (t_w < n_live) n_live = t_w;
+    }
+
+    // ---- per-lane DMA source offsets inside a tile (the image's layout, applied to the SOURCE) -------------------
+    // piece pc = 4 j + wave covers LDS bytes [1024 pc, 1024 pc + 1024) of the tile's image; the matching source bytes
+    // are j * 4096 + (lane constant) for both images and both E (fa_fwd_w64 header).
+    uint32_t k_src, v_src;
+    int k_row, v_row;                                        // tile row this lane copies at j = 0 (rows advance 4096 / row bytes per j)
+    {
+        const int off = wave * 1024 + lane * 16;             // LDS byte inside the image, j = 0
+        const int row = off / KImg::kRowBytes, phys = (off % KImg::kRowBytes) >> 4;
+        k_row = row;
+        k_src = (uint32_t)(row * KImg::kRowBytes + ((phys ^ KImg::xor_of(row)) << 4));
+        const int blk = off >> 8, rg = blk / VImg::kEB, eb = blk % VImg::kEB, rr = (off >> 6) & 3, c4 = (off >> 4) & 3;
+        v_row = 4 * rg + rr;
+        v_src = (uint32_t)(v_row * VImg::kRowBytes + ((4 * eb + c4) << 4));
+    }
+    constexpr int ROWS_PER_J = 4096 / KImg::kRowBytes;
+    // piece j (0 .. NJ-1) of tile `t` (clamped: see below) into ring slot `slot_t % NS`
+    auto issue_piece = [&](const char* gbase, uint32_t ring, int t, int slot_t, uint32_t src, int row0, int j) {
+        const uint32_t dst = ring + (uint32_t)((slot_t % NS) * KBYTES + wave * 1024 + j * 4096);
+        const char* tb = gbase + (size_t)t * TILE_BYTES;
+        bool ragged = false;
+        if constexpr (kGeneral) ragged = (t + 1) * BK > p.KL;
+        if (!ragged) {
+            dma_piece(tb + j * 4096, src, dst);
+        } else {
+            // last, partial tile: rows past KL are copied from row KL-1 (finite data; their logits are masked out)
+            const int rows_valid = p.KL - t * BK;
+            const int row = row0 + j * ROWS_PER_J;
+            const int rc = row < rows_valid ? row : rows_valid - 1;
+            dma_piece_addr(tb + (size_t)rc * KImg::kRowBytes + (src - (uint32_t)(row0 * KImg::kRowBytes)), dst);
+        }
+    };
+    // Past the last tile the LAST tile is copied again (into a ring slot nobody reads any more) instead of branching
+    // around the issue: a branch inside the loop body splits its basic block, and hipcc then sinks the softmax
+    // arithmetic of the earlier slots below the branch, next to its first use (see pin() below).
+    auto issue_k_piece = [&](int t, int j) { issue_piece(kp, kring, t < n_tiles ? t : n_tiles - 1, t, k_src, k_row, j); };
+    auto issue_v_piece = [&](int t, int j) { issue_piece(vp, vring, t < n_tiles ? t : n_tiles - 1, t, v_src, v_row, j); };
+    auto issue_k = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) issue_k_piece(t, j);
+    };
+    auto issue_v = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) issue_v_piece(t, j);
+    };
+
+    // ---- prologue: K(0..2), V(0..1) in flight; Q fragments straight to registers ----------------------------------
+    issue_k(0); issue_v(0); issue_k(1); issue_v(1); issue_k(2);
+    const float c2 = p.scale * kLog2e;
+    frag_t qf[2][KS];                                        // accumulator file, for the whole kernel
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+        const int qc = qi[z] < p.QL ? qi[z] : p.QL - 1;
+        const T* qrow = qp + (size_t)qc * E;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[z][ks] = load_q_frag<frag_t>(qrow + 16 * ks + 8 * h);
+    }
+
+    f32x16 oacc[2][EB];
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[z][eb][i] = 0.f;
+    float m2[2] = {-INFINITY, -INFINITY}, mt[2] = {-INFINITY, -INFINITY};
+    float lp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};               // row sums: two chains per query block
+
+    // ---- LDS fragment reads from integer addresses -------------------------------------------------------------------
+    // K row read (RowImg): row 32 kb + r, 16-byte chunk (2 ks + h) ^ xor_of(row).  xor_of(32 kb + r) = xor_of(r), and with
+    // x = xor_of(r): (2 ks + h) ^ x = (x ^ h) ^ (2 ks), so   addr(kb, ks) = (A ^ (ks << 5)) + kb * 32 * row bytes   with
+    // A = image + r * row bytes + ((x ^ h) << 4): ONE lane-dependent base per iteration, one v_xor per fragment.
+    // V transposed read (ColImg): image + lane_base + compile-time offsets.
+    typedef __attribute__((address_space(3))) const frag_t* lds_frag_p;
+    typedef __attribute__((address_space(3))) s16x4* lds_tr_p;
+    const uint32_t k_lane = (uint32_t)(r * KImg::kRowBytes + ((KImg::xor_of(r) ^ h) << 4));
+    const uint32_t v_lane = (uint32_t)VImg::lane_base(lane);
+    auto read_kfrag = [&](uint32_t ka, int f) -> frag_t {          // ka = image address + k_lane
+        const int kb = f / KS, ks = f % KS;
+        return *(lds_frag_p)(uintptr_t)((ka ^ (uint32_t)(ks << 5)) + (uint32_t)(kb * 32 * KImg::kRowBytes));
+    };
+    auto read_vfrag = [&](uint32_t va, int g) -> frag_t {          // va = image address + v_lane;  g = kk * EB + eb
+        const int kk = g / EB, eb = g % EB;
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(uintptr_t)(va + (uint32_t)(((4 * kk) * VImg::kEB + eb) << 8)));
+        const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(uintptr_t)(va + (uint32_t)(((4 * kk + 2) * VImg::kEB + eb) << 8)));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v8 = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        return __builtin_bit_cast(frag_t, v8);
+    };
+    // per-iteration image bases as opaque registers: everything derived from them is base + immediate (hipcc otherwise
+    // hoists one lane-constant address per fragment out of the loop and runs out of registers)
+    auto opaque = [](uint32_t x) { asm volatile("" : "+v"(x)); return x; };
+    // "computed HERE": hipcc sinks pure arithmetic to the basic block of its first use, i.e. out of the slot it was
+    // placed in and below any branch in between; a value that passes through a volatile statement stays put.
+    auto pin = [](auto& x) { asm volatile("" : "+v"(x)); };
+    // which keys of tile t exist and are valid, wave-uniform (masked mode only)
+    auto tile_valid = [&](int t) -> uint64_t { return kpad_tile_bits<BK>(vbits, t); };
+    auto tile_needs_mask = [&](int t, uint64_t valid) { return valid != kFull || t * BK + BK - 1 > causal_q0; };
+    // causal / padding mask of tile t applied to its raw logits (-> -inf), both query blocks.  Per (z, kb) ONE 32-bit
+    // lane mask: validity bits of the lane's key rows AND the causal prefix (local key row <= lim).
+    auto apply_mask = [&](f32x16 (&s)[2][KB], int t, uint64_t valid) {
+        const int k0 = t * BK;
+#pragma unroll
+        for (int z = 0; z < 2; ++z)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int lim = qlim[z] - k0 - 32 * kb - 4 * h;
+                const uint32_t cm = lim >= 31 ? ~0u : (lim < 0 ? 0u : ((2u << lim) - 1u));
+                const uint32_t m = (uint32_t)(valid >> (32 * kb + 4 * h)) & cm;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int lr = (i & 3) + 8 * (i >> 2);
+                    s[z][kb][i] = ((m >> lr) & 1u) ? s[z][kb][i] : -INFINITY;
+                }
+            }
+    };
+    // row max (log2 units, both lane halves) of one query block's raw score tile
+    auto row_max = [&](const f32x16 (&s)[KB]) -> float {
+        float mxp[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2)
+                mxp[(i >> 1) & 3] = fmaxf(fmaxf(mxp[(i >> 1) & 3], s[kb][i]), s[kb][i + 1]);
+        return half_swap_max(fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3])) * c2);
+    };
+    // Rare path, before a tile is exponentiated: some row's max outgrew the reference by > kThr (or the row sees its
+    // first key) -> raise the reference; everything accumulated at the old one (O, l) is scaled exactly once.
+    auto rescale = [&](const float (&mx)[2]) {
+        bool any = false;
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+            mt[z] = fmaxf(mt[z], mx[z]);
+            any = any || (mx[z] > m2[z] + kThr);
+        }
+        if (__any(any)) {
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                const bool up = mx[z] > m2[z] + kThr;
+                const float mn = up ? mx[z] : m2[z];
+                const float alpha = up ? fast_exp2(m2[z] - mn) : 1.f;     // m2 = -inf -> 0 (nothing accumulated yet)
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb) {
+                    fence_acc_result(oacc[z][eb]);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[z][eb][i] *= alpha;
+                    // back in the accumulator file BEFORE the paths merge: otherwise the merged value is allocated in
+                    // arch VGPRs and the common path pays 128 v_accvgpr_read + 128 v_accvgpr_write per tile for it
+                    asm volatile("" : "+a"(oacc[z][eb]));
+                }
+                lp[z][0] *= alpha;
+                lp[z][1] *= alpha;
+                m2[z] = mn;
+            }
+        }
+    };
+
+    // ---- prologue, continued: wait for the first tiles, S(0) = K(0) Q^T, its mask and row max -----------------------
+    // first tiles and Q landed (every wave's pieces: barrier).  The Q fragments pass through the statement.
+    if constexpr (KS == 8) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                     : "+a"(qf[0][0]), "+a"(qf[0][1]), "+a"(qf[0][2]), "+a"(qf[0][3]), "+a"(qf[0][4]), "+a"(qf[0][5]),
+                       "+a"(qf[0][6]), "+a"(qf[0][7]), "+a"(qf[1][0]), "+a"(qf[1][1]), "+a"(qf[1][2]), "+a"(qf[1][3]),
+                       "+a"(qf[1][4]), "+a"(qf[1][5]), "+a"(qf[1][6]), "+a"(qf[1][7])
+                     :: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                     : "+a"(qf[0][0]), "+a"(qf[0][1]), "+a"(qf[0][2]), "+a"(qf[0][3]), "+a"(qf[1][0]), "+a"(qf[1][1]),
+                       "+a"(qf[1][2]), "+a"(qf[1][3])
+                     :: "memory");
+    }
+
+    f32x16 sa[2][KB], sb[2][KB];                             // score tiles: current / next (roles swap every iteration)
+    float mxa[2] = {-INFINITY, -INFINITY}, mxb[2] = {-INFINITY, -INFINITY};
+    frag_t fr[RF];                                           // fragment ring
+    if (n_live > 0) {
+        const uint32_t ka0 = opaque(kring + k_lane);
+#pragma unroll
+        for (int f = 0; f < NKF; ++f) {
+            const frag_t a = read_kfrag(ka0, f);
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                if (f % KS == 0) sa[z][f / KS] = MM::qk_first(a, qf[z][f % KS]);
+                else MM::qk_acc(sa[z][f / KS], a, qf[z][f % KS]);
+            }
+        }
+        fence_mfma_result(sa[0][0], sa[0][1], sa[1][0], sa[1][1]);
+        if constexpr (kGeneral) {
+            const uint64_t v0 = tile_valid(0);
+            if (tile_needs_mask(0, v0)) apply_mask(sa, 0, v0);
+        }
+        mxa[0] = row_max(sa[0]);
+        mxa[1] = row_max(sa[1]);
+        // fragments 0 .. PF-1 of the first iteration's stream: K(1)
+        const uint32_t ka1 = opaque(kring + (1 % NS) * KBYTES + k_lane);
+#pragma unroll
+        for (int f = 0; f < PF; ++f) fr[f] = read_kfrag(ka1, f);
+    }
+
+    // ---- one iteration: softmax + PV of tile t on `sc` (row max `mxc` known) beside QK^T of tile t+1 into `sn` ------
+    auto iteration = [&](int t, f32x16 (&sc)[2][KB], const float (&mxc)[2], f32x16 (&sn)[2][KB], float (&mxn)[2]) {
+        rescale(mxc);
+        float msub[2];
+#pragma unroll
+        for (int z = 0; z < 2; ++z) msub[z] = (kGeneral && m2[z] == -INFINITY) ? 0.f : m2[z];   // no key seen yet: P = 0
+        const uint32_t kimg = opaque(kring + (uint32_t)(((t + 1) % NS) * KBYTES) + k_lane);    // K(t+1)
+        const uint32_t vimg = opaque(vring + (uint32_t)((t % NS) * VBYTES) + v_lane);          // V(t)
+        const uint32_t kimg2 = opaque(kring + (uint32_t)(((t + 2) % NS) * KBYTES) + k_lane);   // K(t+2): next iteration's first fragments
+        frag_t pf[2 * KB][2];                                     // P^T fragments of tile t: [16-key step kk][z]
+
+        // softmax element n of tile t: chunk c = n / 8 = 2 kk + z, element j = n % 8 of that chunk.  Step n issues the
+        // fma + exp of element n and THEN the row-sum add (and, when it closes a chunk, the 4 converts) of element n - 1:
+        // a consumer directly behind its v_exp_f32 costs a wait state (transcendental-result hazard, s_nop); step 64
+        // only finishes element 63.
+        auto sm_elem = [&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+#if NNOP_W64_ABL != 3
+            if constexpr (n < 64) {
+                constexpr int c = n >> 3, j = n & 7, kk = c >> 1, z = c & 1, kb = kk >> 1, i = 8 * (kk & 1) + j;
+                float e = fast_exp2(__builtin_fmaf(sc[z][kb][i], c2, -msub[z]));
+                pin(e);
+                sc[z][kb][i] = e;
+            }
+            if constexpr (n > 0) {
+                constexpr int m = n - 1, c = m >> 3, j = m & 7, kk = c >> 1, z = c & 1, kb = kk >> 1, i = 8 * (kk & 1) + j;
+                lp[z][j & 1] += sc[z][kb][i];
+                pin(lp[z][j & 1]);
+                if constexpr (j == 7) {
+                    pf[kk][z] = acc_frag<T, (kk & 1)>(sc[z][kb]);
+                    pin(pf[kk][z]);
+                }
+            }
+#else
+            if constexpr (n > 0 && ((n - 1) & 7) == 7) {
+                constexpr int c = (n - 1) >> 3, kk = c >> 1, z = c & 1, kb = kk >> 1;
+                pf[kk][z] = acc_frag<T, (kk & 1)>(sc[z][kb]);
+                pin(pf[kk][z]);
+            }
+#endif
+        };
+        // fragment read PF ahead of stream position f (wraps into the next iteration's K fragments)
+        auto read_ahead = [&](auto fc) {
+            constexpr int g = decltype(fc)::value + PF;
+#if NNOP_W64_ABL != 5
+            if constexpr (g < NKF) fr[g % RF] = read_kfrag(kimg, g);
+            else if constexpr (g < NF) fr[g % RF] = read_vfrag(vimg, g - NKF);
+            else fr[g % RF] = read_kfrag(kimg2, g - NF);
+#endif
+        };
+
+        // row max of tile t+1, one query block, as 17 small items (4 independent v_max3 chains, then the combine) so that
+        // they can be dealt out over the slots: item q < 16 folds two logits, item 16 finishes (scale, lane-half swap)
+        float mxp[2][4];
+        auto mx_item = [&](auto uc) {
+            constexpr int u = decltype(uc)::value, z = u & 1, q = u >> 1;
+#if NNOP_W64_ABL != 4
+            if constexpr (q < 16) {
+                constexpr int kb = q >> 3, i0 = 2 * (q & 7);
+                // single instructions: fmaxf() on values hipcc cannot prove canonical (asm MFMA results) costs an extra
+                // canonicalising v_max_f32 x, x, x per operand
+                if constexpr (q < 4) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mxp[z][q]) : "v"(sn[z][kb][i0]), "v"(sn[z][kb][i0 + 1]));
+                else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mxp[z][q & 3]) : "v"(sn[z][kb][i0]), "v"(sn[z][kb][i0 + 1]));
+            } else {
+                mxn[z] = half_swap_max(fmaxf(fmaxf(mxp[z][0], mxp[z][1]), fmaxf(mxp[z][2], mxp[z][3])) * c2);
+                pin(mxn[z]);
+            }
+#endif
+        };
+
+        // -------- the schedule: which softmax steps (0 .. 64) and row-max items (0 .. 33) each slot carries -------------
+        // Phase X (NX slots, QK^T of tile t+1): steps [0, NEX).  Phase Y (NY slots, PV of tile t): steps [NEX, 65) on
+        // slots [0, NYE); mask of tile t+1 at slot MX0 - 1, its row-max items on slots [MX0, NY); tile barrier at slot
+        // NYB, the DMA batch on the odd slots behind it.
+        constexpr int NEX = E >= 128 ? 44 : 40;
+        constexpr int NYE = E >= 128 ? 22 : 12;
+        constexpr int MX0 = 3, NYB = NY / 2;
+        // deadline: the converts of chunk c = 2 kk + z (step 8 c + 8) sit in a slot BEFORE the first PV MFMA of (kk, z)
+        static_assert(NEX >= 32 + 1, "P^T of kk = 0, 1 is complete when phase Y starts");
+        static_assert((40 + 1 - NEX <= 0) || ((40 + 1 - NEX) * NYE - 1) / (65 - NEX) < 4 * EB, "chunk (kk=2, z=0)");
+        static_assert(((48 + 1 - NEX) * NYE - 1) / (65 - NEX) < 4 * EB + 1, "chunk (kk=2, z=1)");
+        static_assert(((56 + 1 - NEX) * NYE - 1) / (65 - NEX) < 6 * EB, "chunk (kk=3, z=0)");
+        static_assert(NYE <= 6 * EB + 1, "chunk (kk=3, z=1)");
+        static_assert(NY - 2 * PF >= NYB, "K(t+2) fragments are read only after the tile barrier");
+        static_assert(NYB + 4 * NJ <= NY, "the DMA batch fits behind the barrier");
+
+        // -------- phase X ----------------------------------------------------------------------------------------------
+        static_for<NX>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int f = i >> 1, z = i & 1, kb = f / KS, ks = f % KS;
+            if constexpr (z == 0) read_ahead(std::integral_constant<int, f>{});
+            if constexpr (ks == 0) sn[z][kb] = MM::qk_first(fr[f % RF], qf[z][ks]);
+            else MM::qk_acc(sn[z][kb], fr[f % RF], qf[z][ks]);
+            constexpr int n0 = i * NEX / NX, n1 = (i + 1) * NEX / NX;
+            static_for<n1 - n0>([&](auto dn) { sm_elem(std::integral_constant<int, n0 + decltype(dn)::value>{}); });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // -------- phase Y ----------------------------------------------------------------------------------------------
+        // No explicit wait states are needed inside the loop: every P^T fragment is written (v_cvt_pk) at least one slot
+        // (>= one MFMA issue) before the slot whose MFMA reads it, and the score tile `sn` is first read by VALU code two
+        // MFMA slots after the last MFMA that wrote it -- the slot order is pinned by the sched_barrier(0) closing each slot.
+        static_for<NY>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int g = i >> 1, z = i & 1, kk = g / EB, eb = g % EB, f = NKF + g;
+            if constexpr (i == NYB) {
+                // tile barrier: this wave's DMA batch (issued behind the previous barrier) has landed; after the barrier
+                // every wave's has, and every wave is done with the ring slots the next batch overwrites
+#if NNOP_W64_ABL == 2
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+            }
+            // the next batch -- K(t+3), V(t+2): 2 NJ pieces -- one piece per odd slot behind the barrier (an LDS-DMA
+            // instruction occupies the wave's issue for tens of cycles; a burst of 2 NJ of them idles the matrix pipe)
+            if constexpr (i > NYB && ((i - NYB) & 1) == 1 && (i - NYB) / 2 < 2 * NJ) {
+#if NNOP_W64_ABL != 1
+                constexpr int d = (i - NYB) / 2;
+                if constexpr (d < NJ) issue_k_piece(t + 3, d);
+                else issue_v_piece(t + 2, d - NJ);
+#endif
+            }
+            if constexpr (z == 0) read_ahead(std::integral_constant<int, f>{});
+            MM::pv_acc(oacc[z][eb], fr[f % RF], pf[kk][z]);
+            if constexpr (i < NYE) {
+                constexpr int n0 = NEX + i * (65 - NEX) / NYE, n1 = NEX + (i + 1) * (65 - NEX) / NYE;
+                static_for<n1 - n0>([&](auto dn) { sm_elem(std::integral_constant<int, n0 + decltype(dn)::value>{}); });
+            }
+            if constexpr (i == MX0 - 1 && kGeneral) {
+                if (t + 1 < n_live) {
+                    const uint64_t vn = tile_valid(t + 1);
+                    if (tile_needs_mask(t + 1, vn)) apply_mask(sn, t + 1, vn);
+                }
+            }
+            if constexpr (i >= MX0) {
+                constexpr int u0 = (i - MX0) * 34 / (NY - MX0), u1 = (i - MX0 + 1) * 34 / (NY - MX0);
+                static_for<u1 - u0>([&](auto du) { mx_item(std::integral_constant<int, u0 + decltype(du)::value>{}); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    int t = 0;
+    for (; t + 1 < n_live; t += 2) {
+        iteration(t, sa, mxa, sb, mxb);
+        iteration(t + 1, sb, mxb, sa, mxa);
+    }
+    if (t < n_live) {
+        iteration(t, sa, mxa, sb, mxb);
+        ++t;
+    }
+    // waves whose causal range ended early keep the workgroup's DMA / barrier schedule
+    for (; t < n_tiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_k(t + 3);
+        issue_v(t + 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: normalise, store o (16-byte stores: lane halves paired with v_permlane32_swap), ms, ls ------------
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+        const float ltot = half_swap_sum(lp[z][0] + lp[z][1]);
+        const float inv = 1.0f / ltot;                     // ltot == 0 (no visible key) -> NaN rows, as the naive formula gives
+        T* orow = (T*)p.o + ((size_t)bh * p.QL + (qi[z] < p.QL ? qi[z] : p.QL - 1)) * E;
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb) {
+            fence_acc_result(oacc[z][eb]);
+            uint32_t pk[4][2];                             // [g][word]: this lane's 4 elements e = 32 eb + 8 g + 4 h + (0..3)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typedef T t4 __attribute__((ext_vector_type(4)));
+                const f32x4 w = {oacc[z][eb][4 * g] * inv, oacc[z][eb][4 * g + 1] * inv, oacc[z][eb][4 * g + 2] * inv,
+                                 oacc[z][eb][4 * g + 3] * inv};
+                const u32x2 u = __builtin_bit_cast(u32x2, __builtin_convertvector(w, t4));
+                pk[g][0] = u[0];
+                pk[g][1] = u[1];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                // lanes 0-31 end up with e = 32 eb + 8 g + (0..7), lanes 32-63 with e = 32 eb + 8 (g+1) + (0..7)
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                const u32x4 lo = {s0[0], s1[0], s0[1], s1[1]};
+                // s?[0]: vdst after the swap (lower lanes: own g; upper lanes: lower's g+1), s?[1]: src after the swap
+                // (lower lanes: upper's g; upper lanes: own g+1)
+                if (qi[z] < p.QL) *reinterpret_cast<u32x4*>(orow + 32 * eb + 8 * g + 8 * h) = lo;
+            }
+        }
+        if (qi[z] < p.QL && h == 0) {
+            // residual contract (src/attention.jl:128-129): ms = row max (natural-log units) rounded to T, ls relative to
+            // the ROUNDED ms so that the pair stays self-consistent in 16-bit types
+            const size_t so = (size_t)bh * p.QL + qi[z];
+            const T m_t = from_f32<T>(mt[z] * kLn2);
+            const float m_back = to_f32(m_t);
+            float l_out = ltot;
+            if (mt[z] != -INFINITY) l_out = ltot * fast_exp2(m2[z] - m_back * kLog2e);
+            ((T*)p.ms)[so] = m_t;
+            ((T*)p.ls)[so] = from_f32<T>(l_out);
+        }
+    }
+}
+
+}  // namespace nnop
