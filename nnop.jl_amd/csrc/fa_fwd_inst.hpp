@@ -129,9 +129,15 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     // workgroup per CU, else 4 waves x 32 rows so that small problems spread over more CUs.
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
     if constexpr (sizeof(T) == 2 && (E == 64 || E == 128)) {
-        // 64-row waves (fa_fwd_w64.hpp).  Knob kTuneFwdW64: 0 never, 1 wherever instantiated, auto = measured choice
+        // 64-row waves (fa_fwd_w64.hpp): 4 waves x 64 rows, one wave per SIMD with the whole register file.  Measured
+        // (bf16 / fp16, MI355X, profiles/r02/NOTES.md): E = 128 plain +27 %, causal +8 %, variable-length GQA +16 % over the
+        // 32-row forms; E = 64 is VALU-issue-bound in this form and stays on the split-KV / 32-row kernels (-8 .. -20 %).
+        // Needs >= one 256-row workgroup per CU to be worth it, and (masked mode) the per-tile validity words in LDS.
+        // Knob kTuneFwdW64: 0 never, 1 wherever instantiated, auto = the rule above.
         const int w64 = tune_get(kTuneFwdW64);
-        if (mode != 2 && w64 == 1) {
+        const bool fits = mode != 2 && (mode == 0 || d.kl <= 64 * kMaxMaskTiles);
+        const bool pays = E == 128 && wg256 >= 256;
+        if (fits && (w64 == 1 || (w64 < 0 && pays))) {
             if (mode == 0) return launch_fwd_w64<T, E, 0>(d, a, s);
             return launch_fwd_w64<T, E, 1>(d, a, s);
         }

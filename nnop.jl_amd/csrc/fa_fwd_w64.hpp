@@ -39,6 +39,17 @@
 #ifndef NNOP_W64_ABL
 #define NNOP_W64_ABL 0
 #endif
+// E = 64 only: scale * log2(e) folded into Q (rounded to T once) and the exponent reference -m2 loaded as the INITIAL
+// accumulator of QK^T, so that a logit leaves the matrix pipe ready for v_exp_f32 (no v_fma per logit).  See the header.
+#ifndef NNOP_W64_PRESCALE
+#define NNOP_W64_PRESCALE 0
+#endif
+#ifndef NNOP_W64_M0_TAIL
+#define NNOP_W64_M0_TAIL "\n\ts_mov_b32 m0, -1"
+#endif
+#ifndef NNOP_W64_RF8
+#define NNOP_W64_RF8 0
+#endif
 #ifndef NNOP_W64_PF64
 #define NNOP_W64_PF64 3
 #endif
@@ -66,6 +77,12 @@ template <typename T> struct MfmaAsm;
             asm(MNEMONIC " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(bq));                                        \
             return d;                                                                                           \
         }                                                                                                       \
+        /* D(vgpr) = A(vgpr) x B(acc file) + C(vgpr), C kept */                                                 \
+        static NNOP_DEV f32x16 qk_init(FRAG a, FRAG bq, const f32x16& c) {                                      \
+            f32x16 d;                                                                                           \
+            asm(MNEMONIC " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(bq), "v"(c));                               \
+            return d;                                                                                           \
+        }                                                                                                       \
         static NNOP_DEV void qk_acc(f32x16& d, FRAG a, FRAG bq) {                                               \
             asm(MNEMONIC " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(bq));                                        \
         }                                                                                                       \
@@ -78,12 +95,16 @@ NNOP_MFMA_ASM(__bf16, bf16x8, "v_mfma_f32_32x32x16_bf16")
 NNOP_MFMA_ASM(_Float16, f16x8, "v_mfma_f32_32x32x16_f16")
 #undef NNOP_MFMA_ASM
 
-// MFMA result (8-pass) -> first non-MFMA reader: 12 wait states that hipcc does not insert after an asm MFMA.  The data
-// dependence through the operands keeps every reader below the statement.
+// MFMA result -> first non-MFMA reader: the wait states hipcc does not insert after an asm MFMA.  The data dependence
+// through the operands keeps every reader below the statement.  64 idle cycles, not the table's 12 states: the last MFMA
+// may itself have been issued behind another one that still occupied the matrix pipe, and its final pass (accumulator
+// registers 12..15) then lands up to two MFMA times after its issue -- measured: with `s_nop 15; s_nop 3` the epilogue
+// read stale registers 13..15 of the last-written O tile in ~0.1 % of the rows, differently from run to run.  All three
+// sites (prologue score tile, rescale, epilogue) run once per workgroup or rarer.
 NNOP_DEV void fence_mfma_result(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
-    asm volatile("s_nop 11" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
-NNOP_DEV void fence_acc_result(f32x16& a) { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(a)); }
+NNOP_DEV void fence_acc_result(f32x16& a) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(a)); }
 // VALU-written registers -> MFMA A/B operand inside an asm statement: 2 wait states
 template <typename F> NNOP_DEV void fence_valu_operand(F& a, F& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
 
@@ -97,17 +118,16 @@ template <typename F> NNOP_DEV F load_q_frag(const void* gptr) {
 }
 
 // one 1-KiB LDS-DMA piece: lane l copies 16 bytes from (sbase + voff) to LDS byte (lds_dst + 16 l); lds_dst wave-uniform.
-// M0 (the DMA's LDS base) is written in the same statement that uses it and restored (the compiler owns M0).
+// M0 (the DMA's LDS base) is written in the same statement that uses it.  It is NOT restored: nothing else in these
+// kernels uses M0 (gfx950 DS instructions need no M0 setup; checked in the generated code -- tools/regs.sh prints any
+// other M0 access), and the save / restore pair was 2 of the 5 scalar instructions each DMA cost the issue-bound wave.
 NNOP_DEV void dma_piece(const char* sbase, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" NNOP_W64_M0_TAIL
+                 :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 // same, every lane with its own 64-bit source address (ragged tiles: rows clamped into the tensor)
 NNOP_DEV void dma_piece_addr(const char* vaddr, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(vaddr), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" NNOP_W64_M0_TAIL :: "v"(vaddr), "s"(lds_dst) : "memory");
 }
 
 template <typename T, int E> constexpr int fa_fwd_w64_lds_bytes(bool masked) {
@@ -131,10 +151,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     constexpr int NVF = 2 * KB * EB;                          // V fragments per tile
     constexpr int NF = NKF + NVF;                             // fragment stream of one iteration
     constexpr int NX = 2 * NKF, NY = 2 * NVF;                 // MFMA slots of phase X / phase Y
-    constexpr int PF = E >= 128 ? NNOP_W64_PF128 : NNOP_W64_PF64, RF = PF < 4 ? 4 : 8;      // fragments read ahead / fragment ring
+    constexpr int PF = E >= 128 ? NNOP_W64_PF128 : NNOP_W64_PF64, RF = (PF < 4 && !NNOP_W64_RF8) ? 4 : 8;      // fragments read ahead / fragment ring
     static_assert(NF % RF == 0, "the fragment ring index must be static across iterations");
     constexpr float kThr = 8.0f;
     constexpr uint64_t kFull = ~0ull;
+    constexpr bool kPre = NNOP_W64_PRESCALE && E == 64;      // logits leave the MFMA as (s * scale * log2e - reference)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -215,9 +236,9 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         v_src = (uint32_t)(v_row * VImg::kRowBytes + ((4 * eb + c4) << 4));
     }
     constexpr int ROWS_PER_J = 4096 / KImg::kRowBytes;
-    // piece j (0 .. NJ-1) of tile `t` (clamped: see below) into ring slot `slot_t % NS`
-    auto issue_piece = [&](const char* gbase, uint32_t ring, int t, int slot_t, uint32_t src, int row0, int j) {
-        const uint32_t dst = ring + (uint32_t)((slot_t % NS) * KBYTES + wave * 1024 + j * 4096);
+    // piece j (0 .. NJ-1) of tile `t` (clamped: see below) into the ring slot at LDS byte `slot`
+    auto issue_piece = [&](const char* gbase, uint32_t slot, int t, uint32_t src, int row0, int j) {
+        const uint32_t dst = slot + (uint32_t)(wave * 1024 + j * 4096);
         const char* tb = gbase + (size_t)t * TILE_BYTES;
         bool ragged = false;
         if constexpr (kGeneral) ragged = (t + 1) * BK > p.KL;
@@ -234,19 +255,28 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // Past the last tile the LAST tile is copied again (into a ring slot nobody reads any more) instead of branching
     // around the issue: a branch inside the loop body splits its basic block, and hipcc then sinks the softmax
     // arithmetic of the earlier slots below the branch, next to its first use (see pin() below).
-    auto issue_k_piece = [&](int t, int j) { issue_piece(kp, kring, t < n_tiles ? t : n_tiles - 1, t, k_src, k_row, j); };
-    auto issue_v_piece = [&](int t, int j) { issue_piece(vp, vring, t < n_tiles ? t : n_tiles - 1, t, v_src, v_row, j); };
-    auto issue_k = [&](int t) {
+    auto issue_k_piece = [&](int t, uint32_t slot, int j) { issue_piece(kp, slot, t < n_tiles ? t : n_tiles - 1, k_src, k_row, j); };
+    auto issue_v_piece = [&](int t, uint32_t slot, int j) { issue_piece(vp, slot, t < n_tiles ? t : n_tiles - 1, v_src, v_row, j); };
+    auto issue_k = [&](int t, uint32_t slot) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) issue_k_piece(t, j);
+        for (int j = 0; j < NJ; ++j) issue_k_piece(t, slot, j);
     };
-    auto issue_v = [&](int t) {
+    auto issue_v = [&](int t, uint32_t slot) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) issue_v_piece(t, j);
+        for (int j = 0; j < NJ; ++j) issue_v_piece(t, slot, j);
+    };
+    // Ring slots (LDS byte addresses) as rotating scalars -- no t % 3 arithmetic in the loop:
+    //   kA, kB, kC = slots of K(t+1), K(t+2), K(t+3) (= K(t)'s, free);   vA, vB, vC = slots of V(t), V(t+1), V(t+2) (free)
+    uint32_t kA = kring + 1 * KBYTES, kB = kring + 2 * KBYTES, kC = kring;
+    uint32_t vA = vring, vB = vring + 1 * VBYTES, vC = vring + 2 * VBYTES;
+    auto rotate_slots = [&]() {
+        const uint32_t k0 = kA, v0 = vA;
+        kA = kB; kB = kC; kC = k0;
+        vA = vB; vB = vC; vC = v0;
     };
 
     // ---- prologue: K(0..2), V(0..1) in flight; Q fragments straight to registers ----------------------------------
-    issue_k(0); issue_v(0); issue_k(1); issue_v(1); issue_k(2);
+    issue_k(0, kC); issue_v(0, vA); issue_k(1, kA); issue_v(1, vB); issue_k(2, kB);
     const float c2 = p.scale * kLog2e;
     frag_t qf[2][KS];                                        // accumulator file, for the whole kernel
 #pragma unroll
@@ -254,7 +284,25 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         const int qc = qi[z] < p.QL ? qi[z] : p.QL - 1;
         const T* qrow = qp + (size_t)qc * E;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[z][ks] = load_q_frag<frag_t>(qrow + 16 * ks + 8 * h);
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (kPre) {
+                const frag_t raw = *reinterpret_cast<const frag_t*>(qrow + 16 * ks + 8 * h);
+                f32x8 w = __builtin_convertvector(raw, f32x8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] *= c2;
+                qf[z][ks] = __builtin_convertvector(w, frag_t);
+            } else {
+                qf[z][ks] = load_q_frag<frag_t>(qrow + 16 * ks + 8 * h);
+            }
+        }
+    }
+    // kPre: -(exponent reference) per query row, broadcast over a 16-register tuple = the initial accumulator of QK^T
+    f32x16 negm[2];
+    if constexpr (kPre) {
+#pragma unroll
+        for (int z = 0; z < 2; ++z)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) negm[z][i] = 0.f;
     }
 
     f32x16 oacc[2][EB];
@@ -323,22 +371,27 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #pragma unroll
             for (int i = 0; i < 16; i += 2)
                 mxp[(i >> 1) & 3] = fmaxf(fmaxf(mxp[(i >> 1) & 3], s[kb][i]), s[kb][i + 1]);
-        return half_swap_max(fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3])) * c2);
+        return half_swap_max(fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3])) * (kPre ? 1.0f : c2));
     };
     // Rare path, before a tile is exponentiated: some row's max outgrew the reference by > kThr (or the row sees its
     // first key) -> raise the reference; everything accumulated at the old one (O, l) is scaled exactly once.
-    auto rescale = [&](const float (&mx)[2]) {
+    // `mx`: row max of the tile in log2 units -- absolute, or (kPre) relative to the reference that was baked into the
+    // tile's logits when its QK^T ran; `sc`: that tile (kPre: re-based onto the new reference here).
+    auto rescale = [&](const float (&mx)[2], f32x16 (&sc)[2][KB]) {
         bool any = false;
+        float mabs[2];
 #pragma unroll
         for (int z = 0; z < 2; ++z) {
-            mt[z] = fmaxf(mt[z], mx[z]);
-            any = any || (mx[z] > m2[z] + kThr);
+            const float base = (kPre && m2[z] != -INFINITY) ? m2[z] : 0.f;      // what the logits of `sc` have subtracted
+            mabs[z] = kPre ? mx[z] + base : mx[z];
+            mt[z] = fmaxf(mt[z], mabs[z]);
+            any = any || (mabs[z] > m2[z] + kThr);
         }
         if (__any(any)) {
 #pragma unroll
             for (int z = 0; z < 2; ++z) {
-                const bool up = mx[z] > m2[z] + kThr;
-                const float mn = up ? mx[z] : m2[z];
+                const bool up = mabs[z] > m2[z] + kThr;
+                const float mn = up ? mabs[z] : m2[z];
                 const float alpha = up ? fast_exp2(m2[z] - mn) : 1.f;     // m2 = -inf -> 0 (nothing accumulated yet)
 #pragma unroll
                 for (int eb = 0; eb < EB; ++eb) {
@@ -351,6 +404,17 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                 }
                 lp[z][0] *= alpha;
                 lp[z][1] *= alpha;
+                if constexpr (kPre) {
+                    const float base = m2[z] != -INFINITY ? m2[z] : 0.f;
+                    const float nbase = mn != -INFINITY ? mn : 0.f;
+                    const float shift = base - nbase;                      // logits already hold -base
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sc[z][kb][i] += shift;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) negm[z][i] = -nbase;
+                }
                 m2[z] = mn;
             }
         }
@@ -381,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             const frag_t a = read_kfrag(ka0, f);
 #pragma unroll
             for (int z = 0; z < 2; ++z) {
-                if (f % KS == 0) sa[z][f / KS] = MM::qk_first(a, qf[z][f % KS]);
+                if (f % KS == 0) sa[z][f / KS] = kPre ? MM::qk_init(a, qf[z][f % KS], negm[z]) : MM::qk_first(a, qf[z][f % KS]);
                 else MM::qk_acc(sa[z][f / KS], a, qf[z][f % KS]);
             }
         }
@@ -393,20 +457,20 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         mxa[0] = row_max(sa[0]);
         mxa[1] = row_max(sa[1]);
         // fragments 0 .. PF-1 of the first iteration's stream: K(1)
-        const uint32_t ka1 = opaque(kring + (1 % NS) * KBYTES + k_lane);
+        const uint32_t ka1 = opaque(kA + k_lane);
 #pragma unroll
         for (int f = 0; f < PF; ++f) fr[f] = read_kfrag(ka1, f);
     }
 
     // ---- one iteration: softmax + PV of tile t on `sc` (row max `mxc` known) beside QK^T of tile t+1 into `sn` ------
     auto iteration = [&](int t, f32x16 (&sc)[2][KB], const float (&mxc)[2], f32x16 (&sn)[2][KB], float (&mxn)[2]) {
-        rescale(mxc);
+        rescale(mxc, sc);
         float msub[2];
 #pragma unroll
         for (int z = 0; z < 2; ++z) msub[z] = (kGeneral && m2[z] == -INFINITY) ? 0.f : m2[z];   // no key seen yet: P = 0
-        const uint32_t kimg = opaque(kring + (uint32_t)(((t + 1) % NS) * KBYTES) + k_lane);    // K(t+1)
-        const uint32_t vimg = opaque(vring + (uint32_t)((t % NS) * VBYTES) + v_lane);          // V(t)
-        const uint32_t kimg2 = opaque(kring + (uint32_t)(((t + 2) % NS) * KBYTES) + k_lane);   // K(t+2): next iteration's first fragments
+        const uint32_t kimg = opaque(kA + k_lane);                // K(t+1)
+        const uint32_t vimg = opaque(vA + v_lane);                // V(t)
+        const uint32_t kimg2 = opaque(kB + k_lane);               // K(t+2): the next iteration's first fragments
         frag_t pf[2 * KB][2];                                     // P^T fragments of tile t: [16-key step kk][z]
 
         // softmax element n of tile t: chunk c = n / 8 = 2 kk + z, element j = n % 8 of that chunk.  Step n issues the
@@ -418,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #if NNOP_W64_ABL != 3
             if constexpr (n < 64) {
                 constexpr int c = n >> 3, j = n & 7, kk = c >> 1, z = c & 1, kb = kk >> 1, i = 8 * (kk & 1) + j;
-                float e = fast_exp2(__builtin_fmaf(sc[z][kb][i], c2, -msub[z]));
+                float e = kPre ? fast_exp2(sc[z][kb][i]) : fast_exp2(__builtin_fmaf(sc[z][kb][i], c2, -msub[z]));
                 pin(e);
                 sc[z][kb][i] = e;
             }
@@ -462,7 +526,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                 if constexpr (q < 4) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mxp[z][q]) : "v"(sn[z][kb][i0]), "v"(sn[z][kb][i0 + 1]));
                 else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mxp[z][q & 3]) : "v"(sn[z][kb][i0]), "v"(sn[z][kb][i0 + 1]));
             } else {
-                mxn[z] = half_swap_max(fmaxf(fmaxf(mxp[z][0], mxp[z][1]), fmaxf(mxp[z][2], mxp[z][3])) * c2);
+                mxn[z] = half_swap_max(fmaxf(fmaxf(mxp[z][0], mxp[z][1]), fmaxf(mxp[z][2], mxp[z][3])) * (kPre ? 1.0f : c2));
                 pin(mxn[z]);
             }
 #endif
@@ -489,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             constexpr int i = decltype(ic)::value;
             constexpr int f = i >> 1, z = i & 1, kb = f / KS, ks = f % KS;
             if constexpr (z == 0) read_ahead(std::integral_constant<int, f>{});
-            if constexpr (ks == 0) sn[z][kb] = MM::qk_first(fr[f % RF], qf[z][ks]);
+            if constexpr (ks == 0) sn[z][kb] = kPre ? MM::qk_init(fr[f % RF], qf[z][ks], negm[z]) : MM::qk_first(fr[f % RF], qf[z][ks]);
             else MM::qk_acc(sn[z][kb], fr[f % RF], qf[z][ks]);
             constexpr int n0 = i * NEX / NX, n1 = (i + 1) * NEX / NX;
             static_for<n1 - n0>([&](auto dn) { sm_elem(std::integral_constant<int, n0 + decltype(dn)::value>{}); });
@@ -516,8 +580,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             if constexpr (i > NYB && ((i - NYB) & 1) == 1 && (i - NYB) / 2 < 2 * NJ) {
 #if NNOP_W64_ABL != 1
                 constexpr int d = (i - NYB) / 2;
-                if constexpr (d < NJ) issue_k_piece(t + 3, d);
-                else issue_v_piece(t + 2, d - NJ);
+                if constexpr (d < NJ) issue_k_piece(t + 3, kC, d);
+                else issue_v_piece(t + 2, vC, d - NJ);
 #endif
             }
             if constexpr (z == 0) read_ahead(std::integral_constant<int, f>{});
@@ -538,22 +602,43 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        rotate_slots();
     };
 
+    // The loop body exists twice (the two score tiles swap roles) plus once more for an odd tile count.  Where these
+    // copies meet -- loop exit, entry of the remainder -- hipcc's register allocator may give an O tile a different
+    // accumulator tuple on either side and copy it on the edge (v_accvgpr_mov), i.e. directly behind the last asm MFMA of
+    // the copy it leaves: a reader hipcc inserts, so it has no wait states in front of it (measured: stale registers 13..15
+    // of one O tile at E = 64).  A wave therefore idles out its last MFMA at the END of the copy it is about to leave, before
+    // the edge (the loop's exit branch leaves from the block that holds the fence); tools/audit_w64.py checks the generated code.
+#ifdef NNOP_W64_NO_LEAVE_FENCE            // self-test of tools/audit_w64.py: it must flag the build without the fences
+    auto leave_fence = []() {};
+#else
+    auto leave_fence = []() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); };
+#endif
     int t = 0;
-    for (; t + 1 < n_live; t += 2) {
-        iteration(t, sa, mxa, sb, mxb);
-        iteration(t + 1, sb, mxb, sa, mxa);
+    if (n_live >= 2) {
+        for (;;) {
+            iteration(t, sa, mxa, sb, mxb);
+            iteration(t + 1, sb, mxb, sa, mxa);
+            t += 2;
+            if (t + 1 >= n_live) {       // the exit edge starts BEHIND the fence
+                leave_fence();
+                break;
+            }
+        }
     }
     if (t < n_live) {
         iteration(t, sa, mxa, sb, mxb);
+        leave_fence();
         ++t;
     }
     // waves whose causal range ended early keep the workgroup's DMA / barrier schedule
     for (; t < n_tiles; ++t) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        issue_k(t + 3);
-        issue_v(t + 2);
+        issue_k(t + 3, kC);
+        issue_v(t + 2, vC);
+        rotate_slots();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

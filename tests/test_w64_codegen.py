@@ -1,0 +1,22 @@
+"""CPU test of GENERATED code: the 64-row forward (csrc/fa_fwd_w64.hpp) issues every MFMA from inline asm, so hipcc neither
+pads wait states behind them nor knows that a register-allocator copy placed behind one reads an accumulator tile whose last
+pass has not landed.  tools/audit_w64.py models the instruction stream (control flow included) and reports such reads, spills,
+scratch and stray M0 uses; this test runs it on the shipped sources -- and on a build with the source-level fences compiled
+out, which it must flag (that is the bug the fences fix: stale accumulator registers 13..15 of one O tile at E = 64)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AUDIT = os.path.join(ROOT, "tools", "audit_w64.py")
+
+
+def test_shipped_w64_kernels_pass_the_audit():
+    r = subprocess.run([sys.executable, AUDIT], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(": OK") == 8          # {bf16, f16} x {E64, E128} x {plain, masked}
+
+
+def test_audit_flags_the_build_without_leave_fences():
+    r = subprocess.run([sys.executable, AUDIT, "--flags", "-DNNOP_W64_NO_LEAVE_FENCE=1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "before the MFMA writing it is done" in r.stdout, r.stdout + r.stderr

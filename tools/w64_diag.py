@@ -1,0 +1,48 @@
+"""dev: where does the 64-row forward differ from the shipped form?  error map by wave / query block / embedding block,
+and run-to-run reproducibility.  usage: w64_diag.py dt:E:L:QH:KH:B"""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+pkg = ge.load_package()
+dev = torch.device("cuda:0")
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+T = pkg._lib.debug_set
+for c in sys.argv[1:] or ["bf16:64:4096:4:4:4"]:
+    dt, E, L, QH, KH, B = c.split(":"); E, L, QH, KH, B = int(E), int(L), int(QH), int(KH), int(B)
+    g = torch.Generator(device=dev).manual_seed(1)
+    q = torch.randn(B, QH, L, E, generator=g, device=dev).to(DT[dt])
+    k = torch.randn(B, KH, L, E, generator=g, device=dev).to(DT[dt])
+    v = torch.randn(B, KH, L, E, generator=g, device=dev).to(DT[dt])
+    outs = []
+    for w in (0, 1, 1, 1):
+        T("fwd_w64", w)
+        o, ms, ls = pkg._flash_attention(q, k, v, causal=False)
+        torch.cuda.synchronize()
+        outs.append(o.float())
+    T("fwd_w64", -1)
+    ref = outs[0]
+    print(c, "run-to-run identical:", [bool(torch.equal(outs[1], x)) for x in outs[2:]])
+    err = (outs[1] - ref).abs()                                   # [B, QH, L, E]
+    bad = err > 0.02 * ref.abs().max()
+    print("  bad elements:", int(bad.sum()), "of", bad.numel(), " max err", float(err.max()))
+    e5 = bad.reshape(B, QH, L // 256, 4, 2, 32, E // 32, 32)     # [b, h, qblk, wave, z, r, eb, c]
+    print("  by wave :", e5.sum(dim=(0, 1, 2, 4, 5, 6, 7)).tolist())
+    print("  by z    :", e5.sum(dim=(0, 1, 2, 3, 5, 6, 7)).tolist())
+    print("  by eb   :", e5.sum(dim=(0, 1, 2, 3, 4, 5, 7)).tolist())
+    print("  by b,h  :", e5.sum(dim=(2, 3, 4, 5, 6, 7)).tolist())
+    print("  by qblk :", e5.sum(dim=(0, 1, 3, 4, 5, 6, 7)).tolist())
+    print("  by col%32:", e5.sum(dim=(0, 1, 2, 3, 4, 5, 6)).tolist())
+    print("  by row%32:", e5.sum(dim=(0, 1, 2, 3, 4, 6, 7)).tolist())
+    # detail of the first few bad rows (eb = last block)
+    idx = bad.any(dim=-1).nonzero()[:4]
+    for (bb, hh, ll) in idx.tolist():
+        a, r_ = outs[1][bb, hh, ll], ref[bb, hh, ll]
+        cols = bad[bb, hh, ll].nonzero().flatten().tolist()
+        print(f"  row b{bb} h{hh} l{ll}: bad cols {cols}")
+        print("    w64:", [round(float(x), 4) for x in a[E - 8:]])
+        print("    ref:", [round(float(x), 4) for x in r_[E - 8:]])
+    rows_bad = bad.any(dim=-1)                                   # [B, QH, L]
+    print("  bad rows per (b,h,qblk 256):", rows_bad.reshape(B, QH, L // 256, 256).sum(-1).flatten().tolist()[:32])
+    rb = rows_bad.reshape(B, QH, L // 256, 4, 2, 32)
+    print("  bad rows by lane r:", rb.sum(dim=(0, 1, 2, 3, 4)).tolist())
