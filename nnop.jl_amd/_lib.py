@@ -53,7 +53,8 @@ EXPORTED_SYMBOLS = (
 # Test-only hooks (csrc/nnop_debug.h): exported by the library, deliberately NOT in the public header.
 DEBUG_SYMBOLS = ("nnop_debug_set", "nnop_debug_dev_build")
 # keys of nnop_debug_set == enum TuneKey (csrc/tuning.hpp)
-TUNE_KEYS = {"fwd_split": 0, "fwd_nw": 1, "fwd_w64": 2, "bwd_big7": 3, "norm_bwd_cap": 4, "bwd_form": 5}
+TUNE_KEYS = {"fwd_split": 0, "fwd_nw": 1, "fwd_w64": 2, "bwd_big7": 3, "norm_bwd_cap": 4, "bwd_form": 5,
+             "fwd_exact_scale": 6}
 
 
 class FaDesc(C.Structure):

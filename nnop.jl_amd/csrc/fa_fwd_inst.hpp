@@ -93,11 +93,11 @@ static int launch_fwd_split(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t
 }
 
 // 64-rows-per-wave form (fa_fwd_w64.hpp): 4 waves x 64 rows, 16-bit types, E = 64 / 128, plain and masked modes
-template <typename T, int E, int MODE>
+template <typename T, int E, int MODE, bool PRE>
 static int launch_fwd_w64(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
     constexpr int lds = fa_fwd_w64_lds_bytes<T, E>(MODE != 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = fa_fwd_w64_kernel<T, E, MODE>;
+    auto kern = fa_fwd_w64_kernel<T, E, MODE, PRE>;
     static unsigned long long lds_done = 0;
     if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
     FwdParams p;
@@ -130,16 +130,21 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
     if constexpr (sizeof(T) == 2 && (E == 64 || E == 128)) {
         // 64-row waves (fa_fwd_w64.hpp): 4 waves x 64 rows, one wave per SIMD with the whole register file.  Measured
-        // (bf16 / fp16, MI355X, profiles/r02/NOTES.md): E = 128 plain +27 %, causal +8 %, variable-length GQA +16 % over the
-        // 32-row forms; E = 64 is VALU-issue-bound in this form and stays on the split-KV / 32-row kernels (-8 .. -20 %).
-        // Needs >= one 256-row workgroup per CU to be worth it, and (masked mode) the per-tile validity words in LDS.
-        // Knob kTuneFwdW64: 0 never, 1 wherever instantiated, auto = the rule above.
+        // against the 32-row forms (bf16 / fp16, MI355X, profiles/r02/NOTES.md): E = 128 plain +32 %, causal +15 %,
+        // variable-length GQA +20 %; E = 64 plain +11 % at the headline shape and +17..26 % on larger grids, causal L >= 4096
+        // +4..17 %.  It needs >= one 256-row workgroup per CU, enough kv tiles to amortise its longer prologue (short or
+        // causal-and-short sequences stay on the 32-row kernels: -3..-20 % there), and (masked mode) the per-tile validity
+        // words in LDS.  Knob kTuneFwdW64: 0 never, 1 wherever instantiated, auto = the rule below.
         const int w64 = tune_get(kTuneFwdW64);
         const bool fits = mode != 2 && (mode == 0 || d.kl <= 64 * kMaxMaskTiles);
-        const bool pays = E == 128 && wg256 >= 256;
+        const bool pays = wg256 >= 256 && (E == 128 ? d.kl >= 512 : (d.causal ? d.kl >= 4096 : d.kl >= 1024));
         if (fits && (w64 == 1 || (w64 < 0 && pays))) {
-            if (mode == 0) return launch_fwd_w64<T, E, 0>(d, a, s);
-            return launch_fwd_w64<T, E, 1>(d, a, s);
+            // scale * log2(e) folded into Q (rounded to T once: every logit carries a relative rounding of 2^-9 in bf16,
+            // 2^-12 in fp16 -- what the reference does to S itself when it scales it in T, src/attention.jl:55) unless the
+            // knob kTuneFwdExactScale asks for the exact fp32 scale inside the exponent (one v_fma per logit: 8-12 % slower)
+            const bool exact = tune_get(kTuneFwdExactScale) == 1;
+            if (mode == 0) return exact ? launch_fwd_w64<T, E, 0, false>(d, a, s) : launch_fwd_w64<T, E, 0, true>(d, a, s);
+            return exact ? launch_fwd_w64<T, E, 1, false>(d, a, s) : launch_fwd_w64<T, E, 1, true>(d, a, s);
         }
     }
     if constexpr (sizeof(T) == 2 && E <= 64) {

@@ -42,10 +42,12 @@
 // E = 64 only: scale * log2(e) folded into Q (rounded to T once) and the exponent reference -m2 loaded as the INITIAL
 // accumulator of QK^T, so that a logit leaves the matrix pipe ready for v_exp_f32 (no v_fma per logit).  See the header.
 #ifndef NNOP_W64_PRESCALE
-#define NNOP_W64_PRESCALE 0
+#define NNOP_W64_PRESCALE 1
 #endif
-#ifndef NNOP_W64_M0_TAIL
-#define NNOP_W64_M0_TAIL "\n\ts_mov_b32 m0, -1"
+// row sums of P on the matrix pipe (ones x P^T, one MFMA per 16-key step and query block, accumulated in the accumulator
+// file) instead of one v_add per logit: in this form the WAVE'S ISSUE is the bound, the matrix pipe has slack
+#ifndef NNOP_W64_MFMASUM
+#define NNOP_W64_MFMASUM 1
 #endif
 #ifndef NNOP_W64_RF8
 #define NNOP_W64_RF8 0
@@ -118,23 +120,24 @@ template <typename F> NNOP_DEV F load_q_frag(const void* gptr) {
 }
 
 // one 1-KiB LDS-DMA piece: lane l copies 16 bytes from (sbase + voff) to LDS byte (lds_dst + 16 l); lds_dst wave-uniform.
+// (The instruction's immediate offset is 13-bit signed: the 4-KiB stride between a wave's pieces does not fit, so each
+// piece has its own per-lane offset register -- loop constants -- instead of per-piece scalar address arithmetic.)
 // M0 (the DMA's LDS base) is written in the same statement that uses it.  It is NOT restored: nothing else in these
-// kernels uses M0 (gfx950 DS instructions need no M0 setup; checked in the generated code -- tools/regs.sh prints any
-// other M0 access), and the save / restore pair was 2 of the 5 scalar instructions each DMA cost the issue-bound wave.
+// kernels uses M0 (gfx950 DS instructions need no M0 setup; tools/audit_w64.py fails the build's test on any other M0
+// access), and the save / restore pair was 2 of the scalar instructions each DMA cost the issue-bound wave.
 NNOP_DEV void dma_piece(const char* sbase, uint32_t voff, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" NNOP_W64_M0_TAIL
-                 :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 // same, every lane with its own 64-bit source address (ragged tiles: rows clamped into the tensor)
 NNOP_DEV void dma_piece_addr(const char* vaddr, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" NNOP_W64_M0_TAIL :: "v"(vaddr), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vaddr), "s"(lds_dst) : "memory");
 }
 
 template <typename T, int E> constexpr int fa_fwd_w64_lds_bytes(bool masked) {
     return 3 * (RowImg<T, E>::bytes(64) + ColImg<T, E>::bytes(64)) + (masked ? 16 + 8 * kMaxMaskTiles : 0);
 }
 
-template <typename T, int E, int MODE>
+template <typename T, int E, int MODE, bool PRE>
 __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     static_assert(sizeof(T) == 2 && (E == 64 || E == 128), "16-bit element types, E = 64 or 128");
     using frag_t = typename Elem<T>::frag;
@@ -155,7 +158,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     static_assert(NF % RF == 0, "the fragment ring index must be static across iterations");
     constexpr float kThr = 8.0f;
     constexpr uint64_t kFull = ~0ull;
-    constexpr bool kPre = NNOP_W64_PRESCALE && E == 64;      // logits leave the MFMA as (s * scale * log2e - reference)
+    constexpr bool kPre = PRE && NNOP_W64_PRESCALE != 0;     // logits leave the MFMA as (s * scale * log2e - reference)
+    constexpr bool kSum = NNOP_W64_MFMASUM != 0 && E <= 64;  // row sums on the matrix pipe (E = 128: measured 1.7 % slower)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -236,34 +240,38 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         v_src = (uint32_t)(v_row * VImg::kRowBytes + ((4 * eb + c4) << 4));
     }
     constexpr int ROWS_PER_J = 4096 / KImg::kRowBytes;
-    // piece j (0 .. NJ-1) of tile `t` (clamped: see below) into the ring slot at LDS byte `slot`
-    auto issue_piece = [&](const char* gbase, uint32_t slot, int t, uint32_t src, int row0, int j) {
-        const uint32_t dst = slot + (uint32_t)(wave * 1024 + j * 4096);
-        const char* tb = gbase + (size_t)t * TILE_BYTES;
-        bool ragged = false;
-        if constexpr (kGeneral) ragged = (t + 1) * BK > p.KL;
+    // piece j (0 .. NJ-1) of the tile at `tb` (`ragged`: its rows past KL do not exist) into the ring slot at LDS byte `slot`
+    auto issue_piece = [&](const char* tb, bool ragged, int rows_valid, uint32_t slot, uint32_t src, int row0, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const uint32_t dst0 = slot + (uint32_t)(wave * 1024);
         if (!ragged) {
-            dma_piece(tb + j * 4096, src, dst);
+            dma_piece(tb, src + (uint32_t)(j * 4096), dst0 + j * 4096);
         } else {
             // last, partial tile: rows past KL are copied from row KL-1 (finite data; their logits are masked out)
-            const int rows_valid = p.KL - t * BK;
             const int row = row0 + j * ROWS_PER_J;
             const int rc = row < rows_valid ? row : rows_valid - 1;
-            dma_piece_addr(tb + (size_t)rc * KImg::kRowBytes + (src - (uint32_t)(row0 * KImg::kRowBytes)), dst);
+            dma_piece_addr(tb + (size_t)rc * KImg::kRowBytes + (src - (uint32_t)(row0 * KImg::kRowBytes)), dst0 + j * 4096);
         }
     };
     // Past the last tile the LAST tile is copied again (into a ring slot nobody reads any more) instead of branching
     // around the issue: a branch inside the loop body splits its basic block, and hipcc then sinks the softmax
     // arithmetic of the earlier slots below the branch, next to its first use (see pin() below).
-    auto issue_k_piece = [&](int t, uint32_t slot, int j) { issue_piece(kp, slot, t < n_tiles ? t : n_tiles - 1, k_src, k_row, j); };
-    auto issue_v_piece = [&](int t, uint32_t slot, int j) { issue_piece(vp, slot, t < n_tiles ? t : n_tiles - 1, v_src, v_row, j); };
+    struct TileSrc { const char* tb; bool ragged; int rows_valid; };
+    auto tile_src = [&](const char* gbase, int t) {
+        const int tc = t < n_tiles ? t : n_tiles - 1;
+        TileSrc r;
+        r.tb = gbase + (size_t)tc * TILE_BYTES;
+        r.ragged = kGeneral && (tc + 1) * BK > p.KL;
+        r.rows_valid = p.KL - tc * BK;
+        return r;
+    };
     auto issue_k = [&](int t, uint32_t slot) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) issue_k_piece(t, slot, j);
+        const TileSrc ts = tile_src(kp, t);
+        static_for<NJ>([&](auto jc) { issue_piece(ts.tb, ts.ragged, ts.rows_valid, slot, k_src, k_row, jc); });
     };
     auto issue_v = [&](int t, uint32_t slot) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) issue_v_piece(t, slot, j);
+        const TileSrc ts = tile_src(vp, t);
+        static_for<NJ>([&](auto jc) { issue_piece(ts.tb, ts.ragged, ts.rows_valid, slot, v_src, v_row, jc); });
     };
     // Ring slots (LDS byte addresses) as rotating scalars -- no t % 3 arithmetic in the loop:
     //   kA, kB, kC = slots of K(t+1), K(t+2), K(t+3) (= K(t)'s, free);   vA, vB, vC = slots of V(t), V(t+1), V(t+2) (free)
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     };
 
     // ---- prologue: K(0..2), V(0..1) in flight; Q fragments straight to registers ----------------------------------
-    issue_k(0, kC); issue_v(0, vA); issue_k(1, kA); issue_v(1, vB); issue_k(2, kB);
+    issue_k(0, kC);                                          // K(0) first: S(0) needs only K(0) and Q
     const float c2 = p.scale * kLog2e;
     frag_t qf[2][KS];                                        // accumulator file, for the whole kernel
 #pragma unroll
@@ -296,6 +304,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             }
         }
     }
+    issue_v(0, vA); issue_k(1, kA); issue_v(1, vB); issue_k(2, kB);      // 4 NJ pieces that may still be in flight below
     // kPre: -(exponent reference) per query row, broadcast over a 16-register tuple = the initial accumulator of QK^T
     f32x16 negm[2];
     if constexpr (kPre) {
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         for (int z = 0; z < 2; ++z)
 #pragma unroll
             for (int i = 0; i < 16; ++i) negm[z][i] = 0.f;
+        fence_valu_operand(negm[0], negm[1]);               // VALU-written -> MFMA operand: 2 wait states, and opaque
     }
 
     f32x16 oacc[2][EB];
@@ -313,7 +323,21 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[z][eb][i] = 0.f;
     float m2[2] = {-INFINITY, -INFINITY}, mt[2] = {-INFINITY, -INFINITY};
-    float lp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};               // row sums: two chains per query block
+    float lp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};               // row sums (VALU form): two chains per query block
+    f32x16 lacc[2];                                          // row sums (matrix-pipe form): every register = sum_k P[k][query]
+    frag_t ones;
+    if constexpr (kSum) {
+#pragma unroll
+        for (int z = 0; z < 2; ++z)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lacc[z][i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = from_f32<T>(1.0f);
+        // opaque: as a known constant hipcc re-materialises it (v_mov) right in front of the asm MFMA that reads it -- a
+        // VALU write -> MFMA operand read without the 2 wait states (measured: garbage row sums of query block 0 only,
+        // the first of the two MFMAs behind the v_movs).  tools/audit_w64.py checks for this pattern.
+        asm volatile("" : "+v"(ones));
+    }
 
     // ---- LDS fragment reads from integer addresses -------------------------------------------------------------------
     // K row read (RowImg): row 32 kb + r, 16-byte chunk (2 ks + h) ^ xor_of(row).  xor_of(32 kb + r) = xor_of(r), and with
@@ -377,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // first key) -> raise the reference; everything accumulated at the old one (O, l) is scaled exactly once.
     // `mx`: row max of the tile in log2 units -- absolute, or (kPre) relative to the reference that was baked into the
     // tile's logits when its QK^T ran; `sc`: that tile (kPre: re-based onto the new reference here).
-    auto rescale = [&](const float (&mx)[2], f32x16 (&sc)[2][KB]) {
+    auto rescale = [&](const float (&mx)[2], f32x16 (&sc)[2][KB], bool first) {
         bool any = false;
         float mabs[2];
 #pragma unroll
@@ -393,17 +417,26 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                 const bool up = mabs[z] > m2[z] + kThr;
                 const float mn = up ? mabs[z] : m2[z];
                 const float alpha = up ? fast_exp2(m2[z] - mn) : 1.f;     // m2 = -inf -> 0 (nothing accumulated yet)
+                if (!first) {                                             // first tile: O and l are still zero
 #pragma unroll
-                for (int eb = 0; eb < EB; ++eb) {
-                    fence_acc_result(oacc[z][eb]);
+                    for (int eb = 0; eb < EB; ++eb) {
+                        fence_acc_result(oacc[z][eb]);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) oacc[z][eb][i] *= alpha;
-                    // back in the accumulator file BEFORE the paths merge: otherwise the merged value is allocated in
-                    // arch VGPRs and the common path pays 128 v_accvgpr_read + 128 v_accvgpr_write per tile for it
-                    asm volatile("" : "+a"(oacc[z][eb]));
+                        for (int i = 0; i < 16; ++i) oacc[z][eb][i] *= alpha;
+                        // back in the accumulator file BEFORE the paths merge: otherwise the merged value is allocated in
+                        // arch VGPRs and the common path pays 128 v_accvgpr_read + 128 v_accvgpr_write per tile for it
+                        asm volatile("" : "+a"(oacc[z][eb]));
+                    }
+                    if constexpr (kSum) {
+                        fence_acc_result(lacc[z]);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) lacc[z][i] *= alpha;
+                        asm volatile("" : "+a"(lacc[z]));
+                    } else {
+                        lp[z][0] *= alpha;
+                        lp[z][1] *= alpha;
+                    }
                 }
-                lp[z][0] *= alpha;
-                lp[z][1] *= alpha;
                 if constexpr (kPre) {
                     const float base = m2[z] != -INFINITY ? m2[z] : 0.f;
                     const float nbase = mn != -INFINITY ? mn : 0.f;
@@ -417,19 +450,22 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                 }
                 m2[z] = mn;
             }
+            if constexpr (kPre) fence_valu_operand(negm[0], negm[1]);
         }
     };
 
     // ---- prologue, continued: wait for the first tiles, S(0) = K(0) Q^T, its mask and row max -----------------------
-    // first tiles and Q landed (every wave's pieces: barrier).  The Q fragments pass through the statement.
+    // K(0) and Q landed (every wave's pieces: barrier); the other four tiles of the prologue stay in flight behind the
+    // counted wait while S(0) is computed.  The Q fragments pass through the statement.
+    static_assert(4 * NJ == 16 || 4 * NJ == 8, "vmcnt literal below");
     if constexpr (KS == 8) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier"
                      : "+a"(qf[0][0]), "+a"(qf[0][1]), "+a"(qf[0][2]), "+a"(qf[0][3]), "+a"(qf[0][4]), "+a"(qf[0][5]),
                        "+a"(qf[0][6]), "+a"(qf[0][7]), "+a"(qf[1][0]), "+a"(qf[1][1]), "+a"(qf[1][2]), "+a"(qf[1][3]),
                        "+a"(qf[1][4]), "+a"(qf[1][5]), "+a"(qf[1][6]), "+a"(qf[1][7])
                      :: "memory");
     } else {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier"
                      : "+a"(qf[0][0]), "+a"(qf[0][1]), "+a"(qf[0][2]), "+a"(qf[0][3]), "+a"(qf[1][0]), "+a"(qf[1][1]),
                        "+a"(qf[1][2]), "+a"(qf[1][3])
                      :: "memory");
@@ -456,6 +492,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         }
         mxa[0] = row_max(sa[0]);
         mxa[1] = row_max(sa[1]);
+    }
+    // the rest of the prologue's tiles landed, every wave's pieces
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (n_live > 0) {
         // fragments 0 .. PF-1 of the first iteration's stream: K(1)
         const uint32_t ka1 = opaque(kA + k_lane);
 #pragma unroll
@@ -464,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 
     // ---- one iteration: softmax + PV of tile t on `sc` (row max `mxc` known) beside QK^T of tile t+1 into `sn` ------
     auto iteration = [&](int t, f32x16 (&sc)[2][KB], const float (&mxc)[2], f32x16 (&sn)[2][KB], float (&mxn)[2]) {
-        rescale(mxc, sc);
+        rescale(mxc, sc, t == 0);
         float msub[2];
 #pragma unroll
         for (int z = 0; z < 2; ++z) msub[z] = (kGeneral && m2[z] == -INFINITY) ? 0.f : m2[z];   // no key seen yet: P = 0
@@ -472,6 +512,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         const uint32_t vimg = opaque(vA + v_lane);                // V(t)
         const uint32_t kimg2 = opaque(kB + k_lane);               // K(t+2): the next iteration's first fragments
         frag_t pf[2 * KB][2];                                     // P^T fragments of tile t: [16-key step kk][z]
+        const TileSrc ksrc = tile_src(kp, t + 3), vsrc = tile_src(vp, t + 2);   // this iteration's DMA batch
 
         // softmax element n of tile t: chunk c = n / 8 = 2 kk + z, element j = n % 8 of that chunk.  Step n issues the
         // fma + exp of element n and THEN the row-sum add (and, when it closes a chunk, the 4 converts) of element n - 1:
@@ -488,8 +529,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             }
             if constexpr (n > 0) {
                 constexpr int m = n - 1, c = m >> 3, j = m & 7, kk = c >> 1, z = c & 1, kb = kk >> 1, i = 8 * (kk & 1) + j;
-                lp[z][j & 1] += sc[z][kb][i];
-                pin(lp[z][j & 1]);
+                if constexpr (!kSum) {
+                    lp[z][j & 1] += sc[z][kb][i];
+                    pin(lp[z][j & 1]);
+                }
                 if constexpr (j == 7) {
                     pf[kk][z] = acc_frag<T, (kk & 1)>(sc[z][kb]);
                     pin(pf[kk][z]);
@@ -533,20 +576,24 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         };
 
         // -------- the schedule: which softmax steps (0 .. 64) and row-max items (0 .. 33) each slot carries -------------
-        // Phase X (NX slots, QK^T of tile t+1): steps [0, NEX).  Phase Y (NY slots, PV of tile t): steps [NEX, 65) on
-        // slots [0, NYE); mask of tile t+1 at slot MX0 - 1, its row-max items on slots [MX0, NY); tile barrier at slot
-        // NYB, the DMA batch on the odd slots behind it.
-        constexpr int NEX = E >= 128 ? 44 : 40;
-        constexpr int NYE = E >= 128 ? 22 : 12;
-        constexpr int MX0 = 3, NYB = NY / 2;
-        // deadline: the converts of chunk c = 2 kk + z (step 8 c + 8) sit in a slot BEFORE the first PV MFMA of (kk, z)
+        // Phase X (NX slots, QK^T of tile t+1): steps [0, NEX).  Phase Y (NY2 slots: per 16-key step kk first the two
+        // row-sum MFMAs (kSum), then the 2 EB PV MFMAs): steps [NEX, 65) on slots [0, NYE); mask of tile t+1 at slot
+        // MX0 - 1, its row-max items on slots [MX0, NY2); tile barrier at slot NYB, the DMA batch on the odd slots behind it.
+        constexpr int G = 2 * EB + (kSum ? 2 : 0);                // slots per 16-key step
+        constexpr int NY2 = 4 * G;
+        constexpr int NEX = kSum ? 40 : (E >= 128 ? 44 : 40);
+        constexpr int NYE = kSum ? (E >= 128 ? 28 : 17) : (E >= 128 ? 22 : 12);
+        constexpr int MX0 = 3, NYB = NY2 / 2;
+        // deadline: the converts of chunk c = 2 kk + z (step 8 c + 8) sit in a slot BEFORE the first MFMA that reads P^T(kk, z)
+        // (slot kk G + z).  Step s of phase Y lands in a slot <= ((s - NEX + 1) NYE - 1) / (65 - NEX).
         static_assert(NEX >= 32 + 1, "P^T of kk = 0, 1 is complete when phase Y starts");
-        static_assert((40 + 1 - NEX <= 0) || ((40 + 1 - NEX) * NYE - 1) / (65 - NEX) < 4 * EB, "chunk (kk=2, z=0)");
-        static_assert(((48 + 1 - NEX) * NYE - 1) / (65 - NEX) < 4 * EB + 1, "chunk (kk=2, z=1)");
-        static_assert(((56 + 1 - NEX) * NYE - 1) / (65 - NEX) < 6 * EB, "chunk (kk=3, z=0)");
-        static_assert(NYE <= 6 * EB + 1, "chunk (kk=3, z=1)");
-        static_assert(NY - 2 * PF >= NYB, "K(t+2) fragments are read only after the tile barrier");
-        static_assert(NYB + 4 * NJ <= NY, "the DMA batch fits behind the barrier");
+        static_assert((40 + 1 - NEX <= 0) || ((40 + 1 - NEX) * NYE - 1) / (65 - NEX) < 2 * G, "chunk (kk=2, z=0)");
+        static_assert(((48 + 1 - NEX) * NYE - 1) / (65 - NEX) < 2 * G + 1, "chunk (kk=2, z=1)");
+        static_assert(((56 + 1 - NEX) * NYE - 1) / (65 - NEX) < 3 * G, "chunk (kk=3, z=0)");
+        static_assert(NYE <= 3 * G + 1, "chunk (kk=3, z=1)");
+        // the first fragment of K(t+2) is read ahead from the PV slot of V fragment NVF - PF: behind the tile barrier
+        static_assert(((NVF - PF) / EB) * G + (kSum ? 2 : 0) + 2 * ((NVF - PF) % EB) >= NYB, "K(t+2) reads behind the barrier");
+        static_assert(NYB + 4 * NJ <= NY2, "the DMA batch fits behind the barrier");
 
         // -------- phase X ----------------------------------------------------------------------------------------------
         static_for<NX>([&](auto ic) {
@@ -563,9 +610,12 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         // No explicit wait states are needed inside the loop: every P^T fragment is written (v_cvt_pk) at least one slot
         // (>= one MFMA issue) before the slot whose MFMA reads it, and the score tile `sn` is first read by VALU code two
         // MFMA slots after the last MFMA that wrote it -- the slot order is pinned by the sched_barrier(0) closing each slot.
-        static_for<NY>([&](auto ic) {
+        static_for<NY2>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            constexpr int g = i >> 1, z = i & 1, kk = g / EB, eb = g % EB, f = NKF + g;
+            constexpr int kk = i / G, w = i % G;
+            constexpr bool is_sum = kSum && w < 2;
+            constexpr int wp = w - (kSum ? 2 : 0);                // position among the PV slots of this kk
+            constexpr int z = is_sum ? w : (wp & 1), eb = is_sum ? 0 : (wp >> 1), g = kk * EB + eb, f = NKF + g;
             if constexpr (i == NYB) {
                 // tile barrier: this wave's DMA batch (issued behind the previous barrier) has landed; after the barrier
                 // every wave's has, and every wave is done with the ring slots the next batch overwrites
@@ -580,12 +630,16 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             if constexpr (i > NYB && ((i - NYB) & 1) == 1 && (i - NYB) / 2 < 2 * NJ) {
 #if NNOP_W64_ABL != 1
                 constexpr int d = (i - NYB) / 2;
-                if constexpr (d < NJ) issue_k_piece(t + 3, kC, d);
-                else issue_v_piece(t + 2, vC, d - NJ);
+                if constexpr (d < NJ) issue_piece(ksrc.tb, ksrc.ragged, ksrc.rows_valid, kC, k_src, k_row, std::integral_constant<int, d>{});
+                else issue_piece(vsrc.tb, vsrc.ragged, vsrc.rows_valid, vC, v_src, v_row, std::integral_constant<int, d - NJ>{});
 #endif
             }
-            if constexpr (z == 0) read_ahead(std::integral_constant<int, f>{});
-            MM::pv_acc(oacc[z][eb], fr[f % RF], pf[kk][z]);
+            if constexpr (is_sum) {
+                MM::pv_acc(lacc[z], ones, pf[kk][z]);             // ones[32 x 16] x P^T[16 x 32]: every row = sum over the 16 keys
+            } else {
+                if constexpr (z == 0) read_ahead(std::integral_constant<int, f>{});
+                MM::pv_acc(oacc[z][eb], fr[f % RF], pf[kk][z]);
+            }
             if constexpr (i < NYE) {
                 constexpr int n0 = NEX + i * (65 - NEX) / NYE, n1 = NEX + (i + 1) * (65 - NEX) / NYE;
                 static_for<n1 - n0>([&](auto dn) { sm_elem(std::integral_constant<int, n0 + decltype(dn)::value>{}); });
@@ -597,7 +651,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                 }
             }
             if constexpr (i >= MX0) {
-                constexpr int u0 = (i - MX0) * 34 / (NY - MX0), u1 = (i - MX0 + 1) * 34 / (NY - MX0);
+                constexpr int u0 = (i - MX0) * 34 / (NY2 - MX0), u1 = (i - MX0 + 1) * 34 / (NY2 - MX0);
                 static_for<u1 - u0>([&](auto du) { mx_item(std::integral_constant<int, u0 + decltype(du)::value>{}); });
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -645,7 +699,13 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // ---- epilogue: normalise, store o (16-byte stores: lane halves paired with v_permlane32_swap), ms, ls ------------
 #pragma unroll
     for (int z = 0; z < 2; ++z) {
-        const float ltot = half_swap_sum(lp[z][0] + lp[z][1]);
+        float ltot;
+        if constexpr (kSum) {
+            fence_acc_result(lacc[z]);
+            ltot = lacc[z][0];                             // the MFMA already summed the keys of both lane halves
+        } else {
+            ltot = half_swap_sum(lp[z][0] + lp[z][1]);
+        }
         const float inv = 1.0f / ltot;                     // ltot == 0 (no visible key) -> NaN rows, as the naive formula gives
         T* orow = (T*)p.o + ((size_t)bh * p.QL + (qi[z] < p.QL ? qi[z] : p.QL - 1)) * E;
 #pragma unroll

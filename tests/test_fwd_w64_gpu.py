@@ -73,8 +73,8 @@ def test_gqa(pkg, dev, tune, dt, QH, KH, causal):
 @pytest.mark.parametrize("E,causal,pad", [(64, False, None), (64, True, "ref"), (128, False, None), (128, True, "lens")])
 def test_bitwise_reproducible_and_same_residuals_as_the_32_row_form(pkg, dev, tune, dt, E, causal, pad):
     """Repeated launches (caches flushed in between) are bitwise identical -- the screen for races of the LDS-DMA ring and
-    for reads of an accumulator tile before its MFMA has landed (both would come and go with timing); the row max `ms` is the
-    same number in both forms, `o` and `ls` agree to rounding (different summation order of the keys)."""
+    for reads of an accumulator tile before its MFMA has landed (both would come and go with timing); `ms`, `o` agree with the
+    32-row form to rounding (scale folded into Q, different summation order of the keys)."""
     d = make_inputs(75, 2, 4, 2, 1100, 1100, E, dt, dev, pad=pad, need_do=False)
     flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
     tune(fwd_w64=1)
@@ -87,19 +87,29 @@ def test_bitwise_reproducible_and_same_residuals_as_the_32_row_form(pkg, dev, tu
             assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), name
     tune(fwd_w64=0)
     o0, ms0, ls0 = run(pkg, d, causal)
-    assert torch.equal(torch.nan_to_num(outs[0][1].float()), torch.nan_to_num(ms0.float()))
+    # ms: the row max of the scaled logits.  The 64-row form folds scale * log2(e) into Q (rounded to T once), so its max is
+    # the max of slightly different logits: equal to the 32-row form's to the rounding of T (one unit in the last place of
+    # ms itself plus the 2^-9 / 2^-12 relative rounding of the folded Q), not bitwise.
+    m1, m0 = torch.nan_to_num(outs[0][1].float()), torch.nan_to_num(ms0.float())
+    assert float((m1 - m0).abs().max()) <= (1.6e-2 if dt == "bf16" else 2e-3) * float(m0.abs().max())
     scale = float(torch.nan_to_num(o0.float()).abs().max())
     assert float(torch.nan_to_num(outs[0][0].float() - o0.float()).abs().max()) <= (1.5e-2 if dt == "bf16" else 2e-3) * scale
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("E", [64, 128])
+@pytest.mark.parametrize("exact", [0, 1])
 @pytest.mark.parametrize("spike_tiles", [(1,), (2, 5), (0, 3, 4, 9)])
-def test_forced_rescale_of_the_deferred_max(pkg, dev, tune, dt, E, spike_tiles):
+def test_forced_rescale_of_the_deferred_max(pkg, dev, tune, dt, E, exact, spike_tiles):
     """cdna_hip_programming.md rule 26: the rescale branch fires only when a row's max outgrows the exponent reference by 2^8
     -- never on N(0,1) data after the first tile.  Plant keys that are strongly aligned with some queries at chosen kv
     tiles so that the running max jumps by far more than the threshold there, for a subset of the rows of a wave (both
-    query blocks, not all lanes), and compare the FULL output with the oracle."""
+    query blocks, not all lanes), and compare the FULL output with the oracle.
+
+    Both scale forms: `exact` (fp32 scale inside the exponent) must meet the standard tolerance at any logit size; the
+    default form folds scale * log2(e) into Q, so a logit x carries a relative rounding of 2^-9 (bf16) / 2^-12 (fp16): planted
+    logits of |x| ~ 50 .. 200 (log2 units) are then off by up to |x| 2^-9 in the exponent, and the weights of near-tied top
+    keys by that factor -- the error model the tolerance below states (it is what the reference's own `S * scale` in T does)."""
     rng = np.random.default_rng(76)
     B, H, L = 1, 2, 704
     d = make_inputs(77, B, H, H, L, L, E, dt, dev, need_do=False)
@@ -109,11 +119,24 @@ def test_forced_rescale_of_the_deferred_max(pkg, dev, tune, dt, E, spike_tiles):
         key = 64 * t + int(rng.integers(0, 64))
         direction = rng.standard_normal(E).astype(np.float32)
         direction /= np.linalg.norm(direction)
-        gain = 6.0 * (i + 1) * np.sqrt(E)                            # logit * scale ~ 36 (i+1) E / sqrt(E) / ... >> 8 ln 2
+        gain = 6.0 * (i + 1) * np.sqrt(E)
         k[:, :, key] = direction * gain
         q[:, :, rows] = q[:, :, rows] * 0.2 + direction * 6.0
     tdt = d["q"].dtype
     d["q"], d["k"] = torch.tensor(q).to(tdt).to(dev), torch.tensor(k).to(tdt).to(dev)
-    tune(fwd_w64=1)
-    check(pkg, d, False, dt)
-    check(pkg, d, True, dt)
+    tune(fwd_w64=1, fwd_exact_scale=exact)
+    if exact:
+        check(pkg, d, False, dt)
+        check(pkg, d, True, dt)
+        return
+    # folded scale: exponent error <= max|logit| * eps(T) -> relative weight error of tied keys; o is a convex combination
+    # of |v| <= ~4.5, so the element-wise bound is that factor times the value range
+    xmax = 36.0 * len(spike_tiles) * 1.4427                          # largest planted logit, log2 units
+    eps = 2.0 ** -9 if dt == "bf16" else 2.0 ** -12
+    bound = (2.0 ** (xmax * eps) - 1.0) * 4.5 + (2e-2 if dt == "bf16" else 3e-3)
+    for causal in (False, True):
+        o, ms, ls = run(pkg, d, causal)
+        o_ref, ms_ref, ls_ref = oracle_fwd(d, causal)
+        err = np.abs(np.nan_to_num(o.double().cpu().numpy()) - np.nan_to_num(o_ref))
+        assert err.max() <= bound, f"o: max err {err.max():.3e} > error-model bound {bound:.3e}"
+        assert_close("ms", ms, ms_ref, dt, scale=1.0 + xmax * eps / (1e-2))

@@ -14,7 +14,7 @@ AUDIT = os.path.join(ROOT, "tools", "audit_w64.py")
 def test_shipped_w64_kernels_pass_the_audit():
     r = subprocess.run([sys.executable, AUDIT], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(": OK") == 8          # {bf16, f16} x {E64, E128} x {plain, masked}
+    assert r.stdout.count(": OK") == 16         # {bf16, f16} x {E64, E128} x {plain, masked} x {scale folded into Q, exact}
 
 
 def test_audit_flags_the_build_without_leave_fences():

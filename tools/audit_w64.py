@@ -99,6 +99,7 @@ def audit(name, body, meta):
     seen = set()
     for final in (False, True):
         rem, reachable = {}, True                # rem["pipe"]: cycles until the matrix pipe is free
+        fresh = {}                               # register -> age (instructions) of a VALU write, for ages 1, 2
         for l in lines:
             if l.endswith(":"):
                 lab = l[:-1]
@@ -123,6 +124,13 @@ def audit(name, body, meta):
                         del rem[k]
 
             if op.startswith("v_mfma"):
+                # VALU-written register -> MFMA operand needs 2 wait states that hipcc does not know about
+                for a in args[1:]:
+                    for r in reg_list(a):
+                        if r in fresh and final and (l, r) not in seen:
+                            seen.add((l, r))
+                            errs.append(f"`{l}` reads {r[0]}{r[1]} written by the VALU instruction {fresh[r]} instruction(s) before it")
+                fresh = {}
                 advance(rem.get("pipe", 0))      # issue blocks until the pipe is free
                 rem["pipe"] = MFMA_CYCLES
                 for r in reg_list(args[0]):
@@ -148,6 +156,12 @@ def audit(name, body, meta):
             if op in ("s_endpgm", "s_setpc_b64"):
                 reachable = False
                 continue
+            # age the VALU-write window (an s_nop N covers N + 1 wait states), then record this instruction's write
+            age = int(args[0]) + 1 if op == "s_nop" else 1
+            fresh = {r: a + age for r, a in fresh.items() if a + age <= 2}
+            if op.startswith("v_") and not op.startswith("v_cmp") and args:
+                for r in reg_list(args[0]):
+                    fresh[r] = 1 if op != "s_nop" else fresh.get(r, 1)
             advance(cost(op, args))
     return errs
 

@@ -22,6 +22,13 @@ for c in sys.argv[1:] or ["bf16:64:4096:4:4:4"]:
         outs.append(o.float())
     T("fwd_w64", -1)
     ref = outs[0]
+    nan = torch.isnan(outs[1])
+    print("  NaN elements:", int(nan.sum()), " rows with NaN by (b,h):", nan.any(-1).sum(-1).tolist())
+    if nan.any():
+        nr = nan.any(-1).reshape(B, QH, L // 256, 4, 2, 32)
+        print("  NaN rows by wave:", nr.sum(dim=(0, 1, 2, 4, 5)).tolist(), " by z:", nr.sum(dim=(0, 1, 2, 3, 5)).tolist(),
+              " by qblk:", nr.sum(dim=(0, 1, 3, 4, 5)).tolist(), " by lane r:", nr.sum(dim=(0, 1, 2, 3, 4)).tolist())
+        outs[1] = torch.nan_to_num(outs[1])
     print(c, "run-to-run identical:", [bool(torch.equal(outs[1], x)) for x in outs[2:]])
     err = (outs[1] - ref).abs()                                   # [B, QH, L, E]
     bad = err > 0.02 * ref.abs().max()
