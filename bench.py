@@ -8,9 +8,12 @@ Metric (BASELINE.json): attention TFLOP/s (+ GB/s), forward and forward+backward
 E=64, L=4096, H=4, B=4.  Workload at N=1 = BASELINE config C2: bf16, non-causal, forward -- a
 "step" is ONE call of nnop_fa_fwd over one (E,L,H,B) batch of synthetic N(0,1) Q/K/V already
 resident in HBM.  `value` = algorithmic forward FLOPs of all ranks / wall time of the K timed steps
-(max over ranks).  N > 1: one process per GPU, each rank runs the same per-GPU batch (weak scaling
-on the H x B axis -- (batch, head) slices are independent), no data-path
-collective; the optional all-gather of O is timed separately.
+(max over ranks).  N > 1: one process per GPU, no data-path collective ((batch, kv-head) slices are
+independent); the optional all-gather of O is timed separately.
+  --scaling weak   (default, what the driver runs): every rank runs the same per-GPU batch.
+  --scaling strong : the configuration is ONE global problem (C2: 16 (batch, kv-head) units; C5: B = 64)
+                     partitioned with nnop.jl_amd/shard.py `rectangles` -- contiguous unit ranges, <= 3 dense
+                     rectangles per rank, pointer offsets only; a step = the rank's rectangles, one launch each.
 
 Extra objects on the JSON line:
   roofline     -- dominant kernel (fa_fwd_split_kernel at C2): algorithmic FLOPs per launch / average launch
@@ -42,6 +45,11 @@ CONFIGS = {
     "c4": ("f16", 128, 4096, 32, 8, 16, False),          # configs[3]: GQA 32/8, variable sequence length
     "c5": ("bf16", 128, 16384, 32, 32, 8, True),         # configs[4]: ONE GPU's shard (B = 64 / 8) of the 8-GPU config
 }
+# --scaling strong: the GLOBAL problem that is partitioned over the ranks
+GLOBAL_CONFIGS = {
+    "c2": ("bf16", 64, 4096, 4, 4, 4, False),            # 16 units: 8 GPUs -> 2 units each (B < G: split over kv heads)
+    "c5": ("bf16", 128, 16384, 32, 32, 64, True),        # configs[4] itself: B = 64 -> 8 batches per GPU on 8 GPUs
+}
 # C4 lengths: numpy.random.default_rng(0).integers(1024, 4097, size=16)
 C4_LENS = [3637, 2981, 2594, 1853, 1969, 1149, 1255, 1074, 1562, 3523, 3019, 3828, 2571, 2888, 4007, 3265]
 
@@ -55,6 +63,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bwd", action="store_true", help="skip the (untimed-region) fwd+bwd leg")
     ap.add_argument("--gather", action="store_true", help="also time the optional all-gather of O (N>1)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     return ap.parse_args()
 
 
@@ -62,8 +71,10 @@ def cpu_baseline(E, L, H, B):
     """oracle 'port' of benchmarks/main.jl naive attention, fp32, C1 shape, all host cores."""
     import numpy as np
     from oracle.naive_attention import naive_attention_f32, naive_attention_f32_fwd_bwd, attention_flops
+    # all host cores (SURVEY.md section 8(d)); BLAS builds cap their pool (OpenBLAS: 128), so report what was granted
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
+        threadpool_limits(limits=os.cpu_count() or 1)
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:                                   # noqa: BLE001
         threads = os.cpu_count() or 1
@@ -132,14 +143,25 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
     red_dev = torch.device("cpu") if rehearse else dev        # where the timing all-reduce lives
 
-    dtn, E, L, QH, KH, B, causal = CONFIGS[args.config]
+    strong = args.scaling == "strong"
+    if strong and args.config not in GLOBAL_CONFIGS:
+        raise SystemExit("--scaling strong: --config c2 or c5")
+    dtn, E, L, QH, KH, B, causal = (GLOBAL_CONFIGS if strong else CONFIGS)[args.config]
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtn]
+    # this rank's share: weak = the whole per-GPU configuration; strong = its rectangles of (batch, kv-head) units
+    if strong:
+        rects = pkg.shard.rectangles(B, KH, world, rank)
+        shapes = [(r.b1 - r.b0, (r.kh1 - r.kh0) * (QH // KH), r.kh1 - r.kh0) for r in rects]
+    else:
+        shapes = [(B, QH, KH)]
     g = torch.Generator(device=dev).manual_seed(1000 + rank)           # N(0,1), never zeros
-    mk = lambda h: torch.randn(B, h, L, E, generator=g, device=dev, dtype=torch.float32).to(dt)
-    q, k, v, do = mk(QH), mk(KH), mk(KH), mk(QH)
-    o = torch.empty_like(q)
-    ms = torch.empty(B, QH, L, dtype=dt, device=dev)
-    ls = torch.empty_like(ms)
+    mk = lambda b, h: torch.randn(b, h, L, E, generator=g, device=dev, dtype=torch.float32).to(dt)
+    parts = []
+    for (b_, qh_, kh_) in shapes:
+        q, k, v, do = mk(b_, qh_), mk(b_, kh_), mk(b_, kh_), mk(b_, qh_)
+        parts.append(dict(q=q, k=k, v=v, do=do, o=torch.empty_like(q),
+                          ms=torch.empty(b_, qh_, L, dtype=dt, device=dev), ls=torch.empty(b_, qh_, L, dtype=dt, device=dev)))
+    q, k, v, do, o, ms, ls = (parts[0][n] for n in ("q", "k", "v", "do", "o", "ms", "ls")) if parts else (None,) * 7
 
     kpad, kv_lens = None, None
     if args.config == "c4":
@@ -147,7 +169,8 @@ def main():
         kpad = (torch.arange(L, device=dev)[None, :] < torch.tensor(kv_lens, device=dev)[:, None]).contiguous()
 
     def step():
-        pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal, kpad_mask=kpad)
+        for t in parts:
+            pkg.fa_fwd_into(t["o"], t["ms"], t["ls"], t["q"], t["k"], t["v"], causal=causal, kpad_mask=kpad)
 
     def barrier():
         if dist is not None:
@@ -172,16 +195,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t_wall, t_dev = float(t[0]), float(t[1])
 
-    f_fwd = attention_flops(E, L, L, QH, B, causal=causal, kv_lens=kv_lens)
-    by_fwd = attention_bytes(E, L, L, QH, KH, B, q.element_size())
+    esz = 2 if dtn != "f32" else 4
+    f_fwd = attention_flops(E, L, L, QH, B, causal=causal, kv_lens=kv_lens)      # weak: per GPU; strong: the global problem
+    by_fwd = attention_bytes(E, L, L, QH, KH, B, esz)
+    n_rep = 1 if strong else world                       # how many copies of (f_fwd, by_fwd) the job processed per step
     ms_per_step = t_wall / args.steps * 1e3
-    value = world * f_fwd / (t_wall / args.steps) / 1e12
-    kern_s = t_dev / args.steps                          # average launch duration of fa_fwd_kernel
-    achieved = f_fwd / kern_s / 1e12
+    value = n_rep * f_fwd / (t_wall / args.steps) / 1e12
+    # roofline of the dominant kernel, measured on THIS rank (rank 0): its own FLOPs per step / its device time per launch
+    my_b = sum(t["q"].shape[0] * t["q"].shape[1] for t in parts)                  # (batch x q-head) slices of this rank
+    f_mine = f_fwd * my_b // (B * QH) if strong else f_fwd
+    by_mine = by_fwd * my_b // (B * QH) if strong else by_fwd
+    n_launch = max(len(parts), 1)
+    kern_s = t_dev / args.steps / n_launch               # average launch duration
+    achieved = (f_mine / n_launch) / kern_s / 1e12 if parts else 0.0
 
     # ---- fwd+bwd leg (outside the timed region above; same inputs) -----------------------------
     extra = {}
-    if not args.no_bwd:
+    if not args.no_bwd and not strong:
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         ws = torch.empty(pkg.bwd_workspace_bytes(q, k, v, causal=causal), dtype=torch.uint8, device=dev)
         fb = lambda: (pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal, kpad_mask=kpad),
@@ -206,47 +236,65 @@ def main():
             "bwd_tflops": round(world * f_fwd * 2.5 / max(t_fb - kern_s, 1e-9) / 1e12, 2),
             "fwd_bwd_gbps": round(world * by_fb / t_fb / 1e9, 1),
         })
-    if args.gather and dist is not None and not rehearse:
-        full = torch.empty((world,) + tuple(o.shape), dtype=o.dtype, device=dev)
+    if args.gather and dist is not None and (not rehearse or strong):
+        # the one optional collective: replicate the unit-sharded O on every rank (RCCL all-gather over xGMI; gloo in rehearsal)
+        if strong:
+            rep = QH // KH
+            loc = [t["o"].reshape(-1, rep, L, E) for t in parts]
+            local = (torch.cat(loc, dim=0) if len(loc) > 1 else loc[0]) if loc else torch.empty((0, rep, L, E), dtype=dt, device=dev)
+            local = local.cpu() if rehearse else local
+            gat = lambda: pkg.shard.all_gather_units(local, B * KH)
+        else:
+            full = torch.empty((world,) + tuple(o.shape), dtype=o.dtype, device=dev)
+            gat = lambda: dist.all_gather_into_tensor(full, o)
         for _ in range(2):
-            dist.all_gather_into_tensor(full, o)
+            gat()
         barrier()
-        ev0.record()
+        tg0 = time.perf_counter()
         for _ in range(5):
-            dist.all_gather_into_tensor(full, o)
-        ev1.record()
+            gat()
         torch.cuda.synchronize()
-        extra["allgather_o_ms"] = round(ev0.elapsed_time(ev1) / 5, 4)
+        tg = torch.tensor([(time.perf_counter() - tg0) / 5], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        extra["allgather_o_ms"] = round(float(tg[0]) * 1e3, 4)
+        extra["compute_plus_gather_tflops"] = round(n_rep * f_fwd / (t_wall / args.steps + float(tg[0])) / 1e12, 2)
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    traffic = None
+    # HBM bytes per launch from the PMC counters: NOT measured in this run -- the value of the last committed rocprofv3
+    # --pmc collection of this workload (profiles/traffic.json names the run it came from), or null
+    traffic, traffic_src = None, None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj):
+    if os.path.exists(tj) and not strong:
         try:
-            traffic = json.load(open(tj)).get(args.config, {}).get("hbm_bytes_per_launch")
+            ent = json.load(open(tj)).get(args.config, {})
+            traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
         except Exception:                               # noqa: BLE001
             traffic = None
+    fdesc = pkg._lib.FaDesc(dtype={"f32": 0, "f16": 1, "bf16": 2}[dtn], emb=E, ql=L, kl=L, qh=parts[0]["q"].shape[1] if parts else QH,
+                            kh=parts[0]["k"].shape[1] if parts else KH, batch=parts[0]["q"].shape[0] if parts else B,
+                            causal=int(causal), emb_k=0, emb_v=0, kl_v=0, kh_v=0)
+    kernel_name = pkg._lib.fwd_form(fdesc, False, kpad is not None)
     out = {
         "metric": "attention TFLOPs/s + GB/s (fwd, fwd+bwd) at E=64,L=4096,H=4,B=4" if args.config == "c2" else
                   f"attention TFLOPs/s + GB/s (fwd, fwd+bwd), workload {args.config}",
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": dtn, "data": "synthetic",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": dtn, "data": "synthetic",
         "config": {"workload": f"{args.config.upper()}: {dtn} {'causal' if causal else 'non-causal'} "
-                               f"flash_attention forward, E={E} L={L} QH={QH} KH={KH} B={B} per GPU",
-                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world} over (batch, head) slices",
-                   "step": "one nnop_fa_fwd call"},
-        "fwd_gbps": round(world * by_fwd / (t_wall / args.steps) / 1e9, 1),
+                               f"flash_attention forward, E={E} L={L} QH={QH} KH={KH} B={B} " + ("global" if strong else "per GPU"),
+                   "per_gpu_batch": (B if not strong else None), "global_batch": (B if strong else B * world),
+                   "parallelism": f"dp{world} over (batch, kv-head) slices" + (f", {B * KH} units in contiguous ranges" if strong else ""),
+                   "step": "one nnop_fa_fwd call" + (" per rectangle of the rank's unit range" if strong else "")},
+        "fwd_gbps": round(n_rep * by_fwd / (t_wall / args.steps) / 1e9, 1),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[dtn], "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_TFLOPS[dtn], 4), "traffic": traffic,
-                     "kernel": ("fa_fwd_split_kernel" if (dtn != "f32" and E <= 64 and not causal and kpad is None)
-                                else "fa_fwd_kernel"), "avg_launch_us": round(kern_s * 1e6, 2),
-                     "flops_per_launch": f_fwd, "algorithmic_bytes_per_launch": by_fwd,
-                     "hbm_frac_at_this_rate": round(by_fwd / kern_s / 1e9 / HBM_PEAK_GBS, 4)},
+                     "frac": round(achieved / PEAK_TFLOPS[dtn], 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": kernel_name, "avg_launch_us": round(kern_s * 1e6, 2),
+                     "flops_per_launch": f_mine // n_launch, "algorithmic_bytes_per_launch": by_mine // n_launch,
+                     "hbm_frac_at_this_rate": round(by_mine / n_launch / kern_s / 1e9 / HBM_PEAK_GBS, 4)},
     }
     out.update(extra)
     if world == 1 and not args.no_cpu_baseline:

@@ -51,7 +51,8 @@ EXPORTED_SYMBOLS = (
 
 
 # Test-only hooks (csrc/nnop_debug.h): exported by the library, deliberately NOT in the public header.
-DEBUG_SYMBOLS = ("nnop_debug_set", "nnop_debug_dev_build")
+DEBUG_SYMBOLS = ("nnop_debug_set", "nnop_debug_dev_build", "nnop_debug_fwd_form")
+FWD_FORMS = {0: "fa_fwd_kernel", 1: "fa_fwd_split_kernel", 2: "fa_fwd_w64_kernel"}
 # keys of nnop_debug_set == enum TuneKey (csrc/tuning.hpp)
 TUNE_KEYS = {"fwd_split": 0, "fwd_nw": 1, "fwd_w64": 2, "bwd_big7": 3, "norm_bwd_cap": 4, "bwd_form": 5,
              "fwd_exact_scale": 6}
@@ -137,6 +138,8 @@ def load():
     lib.nnop_debug_set.argtypes = [C.c_int, C.c_int]
     lib.nnop_debug_dev_build.restype = C.c_int
     lib.nnop_debug_dev_build.argtypes = []
+    lib.nnop_debug_fwd_form.restype = C.c_int
+    lib.nnop_debug_fwd_form.argtypes = [C.POINTER(FaDesc), C.c_int, C.c_int]
     if lib.nnop_abi_version() != ABI_VERSION:
         raise NNopLibraryMissing(f"{LIB_PATH} has ABI version {lib.nnop_abi_version()}, this binding needs "
                                  f"{ABI_VERSION}: rebuild with `make -C nnop.jl_amd/csrc -j8`")
@@ -158,3 +161,11 @@ def debug_set(key: str, value: int) -> int:
 
 def dev_build() -> bool:
     return bool(load().nnop_debug_dev_build())
+
+
+def fwd_form(desc: FaDesc, has_pair: bool = False, has_mask: bool = False) -> str:
+    """Name of the forward kernel the launcher picks for this problem (reporting only; csrc/nnop_debug.h)."""
+    code = load().nnop_debug_fwd_form(C.byref(desc), int(has_pair), int(has_mask))
+    if code < 0:
+        raise ValueError(strerror(code))
+    return FWD_FORMS[code]

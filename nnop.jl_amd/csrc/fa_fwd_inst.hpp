@@ -121,14 +121,16 @@ static int launch_fwd_mode(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t 
     return launch_fwd_cfg<T, E, NW, 2, QB>(d, a, s);
 }
 
-template <typename T, int E>
-static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
-    // 0 = plain (every logit live), 1 = masked (causal / key padding / ragged KL), 2 = + pair bias
-    const int mode = a.pair ? 2 : ((d.causal || a.kpad || (d.kl % 64) != 0) ? 1 : 0);
-    // Workgroup shape: 8 waves x 32 rows (256-row workgroups) when that still yields >= one
-    // workgroup per CU, else 4 waves x 32 rows so that small problems spread over more CUs.
+// The launcher's choice of kernel form, as a plain function of the descriptor (also reported through nnop_debug_fwd_form).
+//   mode: 0 plain (every logit live), 1 masked (causal / key padding / ragged KL), 2 + pair bias
+static inline int fwd_mode(const nnop_fa_desc& d, bool has_pair, bool has_mask) {
+    return has_pair ? 2 : ((d.causal || has_mask || (d.kl % 64) != 0) ? 1 : 0);
+}
+static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
+    const bool b16 = d.dtype != NNOP_F32;
+    const int E = d.emb;
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
-    if constexpr (sizeof(T) == 2 && (E == 64 || E == 128)) {
+    if (b16 && (E == 64 || E == 128)) {
         // 64-row waves (fa_fwd_w64.hpp): 4 waves x 64 rows, one wave per SIMD with the whole register file.  Measured
         // against the 32-row forms (bf16 / fp16, MI355X, profiles/r02/NOTES.md): E = 128 plain +32 %, causal +15 %,
         // variable-length GQA +20 %; E = 64 plain +11 % at the headline shape and +17..26 % on larger grids, causal L >= 4096
@@ -138,7 +140,26 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
         const int w64 = tune_get(kTuneFwdW64);
         const bool fits = mode != 2 && (mode == 0 || d.kl <= 64 * kMaxMaskTiles);
         const bool pays = wg256 >= 256 && (E == 128 ? d.kl >= 512 : (d.causal ? d.kl >= 4096 : d.kl >= 1024));
-        if (fits && (w64 == 1 || (w64 < 0 && pays))) {
+        if (fits && (w64 == 1 || (w64 < 0 && pays))) return kFormW64;
+    }
+    if (b16 && E <= 64) {
+        // plain mode: 16-wave split-KV workgroups (4 waves per SIMD); measured 5-13 % faster than the 8-wave form from 64 to
+        // 4096 workgroups.  Knob kTuneFwdSplit: 0 off, 1 / auto on; 16 (make DEV=1 builds only) the
+        // v_mfma_16x16x32 body of fa_fwd_split16.hpp -- correct, measured 7 % SLOWER.
+        if (mode == 0 && d.ql > 128 && d.kl >= 128 && tune_get(kTuneFwdSplit) != 0) return kFormSplit;
+    }
+    return kFormRow32;
+}
+
+template <typename T, int E>
+static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+    const int mode = fwd_mode(d, a.pair != nullptr, a.kpad != nullptr);
+    const int form = fwd_form_of(d, mode);
+    // Workgroup shape of the 32-row form: 8 waves x 32 rows (256-row workgroups) when that still yields >= one
+    // workgroup per CU, else 4 waves x 32 rows so that small problems spread over more CUs.
+    const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
+    if constexpr (sizeof(T) == 2 && (E == 64 || E == 128)) {
+        if (form == kFormW64) {
             // scale * log2(e) folded into Q (rounded to T once: every logit carries a relative rounding of 2^-9 in bf16,
             // 2^-12 in fp16 -- what the reference does to S itself when it scales it in T, src/attention.jl:55) unless the
             // knob kTuneFwdExactScale asks for the exact fp32 scale inside the exponent (one v_fma per logit: 8-12 % slower)
@@ -148,14 +169,10 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
         }
     }
     if constexpr (sizeof(T) == 2 && E <= 64) {
-        // default for plain mode: 16-wave split-KV workgroups (4 waves per SIMD); measured 5-13 % faster than
-        // the 8-wave form from 64 to 4096 workgroups.  Knob kTuneFwdSplit: 0 off, 1 / auto on;
-        // 16 (make DEV=1 builds only) the v_mfma_16x16x32 body of fa_fwd_split16.hpp -- correct, measured 7 % SLOWER.
-        const int split = tune_get(kTuneFwdSplit);
-        if (mode == 0 && d.ql > 128 && d.kl >= 128 && split != 0) {
+        if (form == kFormSplit) {
 #ifdef NNOP_DEV_BUILD
             if constexpr (E % 32 == 0) {
-                if (split == 16) return launch_fwd_split<T, E, true>(d, a, s);
+                if (tune_get(kTuneFwdSplit) == 16) return launch_fwd_split<T, E, true>(d, a, s);
             }
 #endif
             return launch_fwd_split<T, E, false>(d, a, s);

@@ -23,6 +23,9 @@ struct BwdArgs {
 
 // One per dtype (fa_fwd_{f32,f16,bf16}.hip).  Return an nnop_status.
 template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s);
+// Which kernel form launch_fwd picks (no launch): 0 = 32-row waves, 1 = split-KV, 2 = 64-row waves.
+enum FwdForm { kFormRow32 = 0, kFormSplit = 1, kFormW64 = 2 };
+int fwd_form(const nnop_fa_desc& d, bool has_pair, bool has_mask);
 // One per dtype (fa_bwd_{f32,f16,bf16}.hip).
 template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s);
 

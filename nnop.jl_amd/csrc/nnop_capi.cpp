@@ -67,6 +67,11 @@ int nnop_debug_set(int key, int value) {
     (void)tune_get(key);                                   // make sure the environment has been parsed first
     return __atomic_exchange_n(&g_tune[key], value, __ATOMIC_RELAXED);
 }
+int nnop_debug_fwd_form(const nnop_fa_desc* d, int has_pair, int has_mask) {
+    const int st = check_desc(d);
+    if (st != NNOP_OK) return st;
+    return fwd_form(*d, has_pair != 0, has_mask != 0);
+}
 int nnop_debug_dev_build(void) {
 #ifdef NNOP_DEV_BUILD
     return 1;

@@ -10,11 +10,17 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+struct nnop_fa_desc;
 
 /* Keys: the TuneKey enumerators of csrc/tuning.hpp (0 fwd_split, 1 fwd_nw, 2 fwd_w64, 3 bwd_big7,
  * 4 norm_bwd_cap, 5 bwd_form, 6 fwd_exact_scale).  value -1 = automatic.  Returns the previous value, or INT_MIN for an
  * unknown key.  Process-wide; takes effect for launches issued after it returns. */
 int nnop_debug_set(int key, int value);
+
+/* Which forward kernel form the launcher picks for this problem (reporting only: bench.py names the kernel its roofline line is
+ * about): 0 = fa_fwd_kernel (32-row waves), 1 = fa_fwd_split_kernel (split-KV), 2 = fa_fwd_w64_kernel (64-row waves),
+ * negative = nnop_status of an invalid descriptor.  has_pair / has_mask: whether pair / kpad_mask would be non-NULL. */
+int nnop_debug_fwd_form(const struct nnop_fa_desc* d, int has_pair, int has_mask);
 
 /* 1 when the library was built with `make DEV=1` (timing ablations, experimental kernel bodies compiled in). */
 int nnop_debug_dev_build(void);
