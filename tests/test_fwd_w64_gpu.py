@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import assert_close, make_inputs, oracle_fwd
+from util import RTOL, assert_close, make_inputs, oracle_fwd
 
 pytestmark = pytest.mark.gpu
 
@@ -139,4 +139,4 @@ def test_forced_rescale_of_the_deferred_max(pkg, dev, tune, dt, E, exact, spike_
         o_ref, ms_ref, ls_ref = oracle_fwd(d, causal)
         err = np.abs(np.nan_to_num(o.double().cpu().numpy()) - np.nan_to_num(o_ref))
         assert err.max() <= bound, f"o: max err {err.max():.3e} > error-model bound {bound:.3e}"
-        assert_close("ms", ms, ms_ref, dt, scale=1.0 + xmax * eps / (1e-2))
+        assert_close("ms", ms, ms_ref, dt, scale=1.0 + xmax * eps / RTOL[dt])

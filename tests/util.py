@@ -8,12 +8,14 @@ import torch
 from oracle.naive_attention import naive_attention, naive_attention_grads
 
 TORCH_DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
-# Tolerances stated by BASELINE.json north_star: fp32 rtol <= 1e-4, fp16/bf16 rtol <= 1e-2,
-# element-wise against the fp64 oracle evaluated on the ROUNDED inputs; atol is scaled to the
-# tensor's max magnitude.
-RTOL = {"f32": 1e-4, "f16": 1e-2, "bf16": 1e-2}
-ATOL_FRAC = {"f32": 1e-5, "f16": 2e-3, "bf16": 1e-2}
-GRAD_SCALE = {"f32": 1.0, "f16": 2.0, "bf16": 2.0}
+# Tolerances: BASELINE.json north_star states the ceiling (fp32 rtol <= 1e-4, fp16/bf16 rtol <= 1e-2), element-wise
+# against the fp64 oracle evaluated on the ROUNDED inputs; atol is scaled to the tensor's max magnitude (SURVEY.md
+# section 8(c)).  The 16-bit values are CALIBRATED: at most ~2x the worst error the whole GPU suite measured (9063
+# comparisons, profiles/r02/parity_errors.json; worst error / tolerance there: bf16 0.49, f16 0.45, f32 0.46), so a
+# regression that doubles the rounding error of any kernel fails.
+RTOL = {"f32": 1e-4, "f16": 4e-3, "bf16": 8e-3}
+ATOL_FRAC = {"f32": 1e-5, "f16": 8e-4, "bf16": 8e-3}
+GRAD_SCALE = {"f32": 1.0, "f16": 2.0, "bf16": 1.6}
 
 
 def make_inputs(seed, B, QH, KH, QL, KL, E, dt, dev, *, pair=False, pad=None, need_do=True):
@@ -57,7 +59,7 @@ def oracle_bwd(d, causal):
 
 # absolute floor for results dominated by cancellation of O(1) terms (e.g. dS = P (dP - delta) == 0 exactly when a
 # row sees a single key): a few rounding units of the O(1) operands, summed over up to a few hundred rows
-ABS_FLOOR = {"f32": 1e-5, "f16": 1e-2, "bf16": 6e-2}
+ABS_FLOOR = {"f32": 1e-5, "f16": 5e-3, "bf16": 4e-2}
 
 
 def record_error(kind, rec):
