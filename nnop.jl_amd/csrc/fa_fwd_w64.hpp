@@ -31,13 +31,22 @@
 #include <utility>
 #include "fa_fwd.hpp"
 
-// timing-only ablations of the hand-placed loop (make DEV=1 VAR=-DNNOP_W64_ABL=n; results WRONG by construction):
-//   1 no LDS-DMA in the loop   2 no tile barrier   3 no softmax arithmetic   4 no row max   5 no LDS fragment reads
+// timing-only ablations of the hand-placed loop (make DEV=1 VAR=-DNNOP_W64_ABL=mask; results WRONG by construction), a bit mask:
+//   1 no LDS-DMA in the loop   2 no tile barrier   4 no softmax arithmetic   8 no row max   16 no LDS fragment reads
 #if !defined(NNOP_DEV_BUILD)
 #undef NNOP_W64_ABL
 #endif
 #ifndef NNOP_W64_ABL
 #define NNOP_W64_ABL 0
+#endif
+// diagnostic (make DEV=1 VAR=-DNNOP_W64_STAMP=1; results WRONG by construction): wave 0 of every workgroup overwrites the
+// start of its first output row with s_memtime / s_memrealtime stamps (kernel entry, loop entry, loop exit, end) --
+// tools/w64_stamp.py turns them into cycles per kv tile and the in-kernel clock (MI355X_MICROARCH.md, "in-kernel clock")
+#if !defined(NNOP_DEV_BUILD)
+#undef NNOP_W64_STAMP
+#endif
+#ifndef NNOP_W64_STAMP
+#define NNOP_W64_STAMP 0
 #endif
 // E = 64 only: scale * log2(e) folded into Q (rounded to T once) and the exponent reference -m2 loaded as the INITIAL
 // accumulator of QK^T, so that a logit leaves the matrix pipe ready for v_exp_f32 (no v_fma per logit).  See the header.
@@ -51,6 +60,14 @@
 #endif
 #ifndef NNOP_W64_RF8
 #define NNOP_W64_RF8 0
+#endif
+// o stored with the nontemporal hint (streamed past L2: less dirty data to write back when the kernel ends)
+#ifndef NNOP_W64_NT
+#define NNOP_W64_NT 0
+#endif
+// softmax: how many exp issues lie between an element's v_exp_f32 and its first consumer (row-sum add / convert)
+#ifndef NNOP_W64_LAG
+#define NNOP_W64_LAG 3
 #endif
 #ifndef NNOP_W64_PF64
 #define NNOP_W64_PF64 3
@@ -70,27 +87,29 @@ template <int... I, typename F> NNOP_DEV void static_for_impl(std::integer_seque
 template <int N, typename F> NNOP_DEV void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // ---- inline-asm MFMAs with explicit register files ------------------------------------------------------------------
+// volatile: an MFMA keeps its place among the other volatile statements of its slot (the pins of the softmax work) -- hipcc
+// otherwise sinks it below the slot's VALU work, and the matrix pipe idles meanwhile.
 template <typename T> struct MfmaAsm;
 #define NNOP_MFMA_ASM(TYPE, FRAG, MNEMONIC)                                                                     \
     template <> struct MfmaAsm<TYPE> {                                                                          \
         /* D(vgpr) = A(vgpr) x B(acc file) */                                                                   \
         static NNOP_DEV f32x16 qk_first(FRAG a, FRAG bq) {                                                      \
             f32x16 d;                                                                                           \
-            asm(MNEMONIC " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(bq));                                        \
+            asm volatile(MNEMONIC " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(bq));                                        \
             return d;                                                                                           \
         }                                                                                                       \
         /* D(vgpr) = A(vgpr) x B(acc file) + C(vgpr), C kept */                                                 \
         static NNOP_DEV f32x16 qk_init(FRAG a, FRAG bq, const f32x16& c) {                                      \
             f32x16 d;                                                                                           \
-            asm(MNEMONIC " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(bq), "v"(c));                               \
+            asm volatile(MNEMONIC " %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(bq), "v"(c));                               \
             return d;                                                                                           \
         }                                                                                                       \
         static NNOP_DEV void qk_acc(f32x16& d, FRAG a, FRAG bq) {                                               \
-            asm(MNEMONIC " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(bq));                                        \
+            asm volatile(MNEMONIC " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(bq));                                        \
         }                                                                                                       \
         /* O(acc file) += A(vgpr) x B(vgpr) */                                                                  \
         static NNOP_DEV void pv_acc(f32x16& o, FRAG a, FRAG b) {                                                \
-            asm(MNEMONIC " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                         \
+            asm volatile(MNEMONIC " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                         \
         }                                                                                                       \
     };
 NNOP_MFMA_ASM(__bf16, bf16x8, "v_mfma_f32_32x32x16_bf16")
@@ -133,6 +152,97 @@ NNOP_DEV void dma_piece_addr(const char* vaddr, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vaddr), "s"(lds_dst) : "memory");
 }
 
+// ---- the slot plan ------------------------------------------------------------------------------------------------
+// One iteration of the loop is NX + NY2 "slots" (one MFMA each).  Besides its MFMA a slot carries fixed work (the LDS
+// fragment read-ahead, an LDS-DMA piece, ...) and a share of two streams of movable work: the softmax steps of tile t
+// (0 .. 63 + LAG: step n issues the exp of element n and finishes element n - LAG -- row-sum add, and the 16-bit convert of
+// the pair it closes) and the row-max items of tile t + 1.  A wave issues in order: a slot lasts max(32, 8 + issue cost of its
+// fillers) cycles (v_exp_f32 8, other VALU / DS / scalar 4, an LDS-DMA piece ~24 with its M0 setup: MI355X_MICROARCH.md,
+// tools/w64_gaps.py), so the streams are dealt out by COST: the smallest per-slot budget `cap` for which a greedy in-order
+// fill places everything inside its window -- a softmax step no later than the slot before the first MFMA that reads the P^T
+// word it completes; a row-max item no earlier than two slots behind the last MFMA that writes the logits it reads.
+template <int E, bool SUM, bool MASKED, int NJ, int LAG> struct W64Plan {
+    static constexpr int KS = E / 16, EB = E / 32, NKF = 2 * KS;
+    static constexpr int NX = 2 * NKF, G = 2 * EB + (SUM ? 2 : 0), NY2 = 4 * G, NSLOT = NX + NY2, NYB = NY2 / 2;
+    static constexpr int NSTEP = 64 + LAG, NMX = 34;
+    static constexpr int MASK_SLOT = NX + 2;            // masked mode: tile t+1 is masked here, its row max starts behind it
+    static constexpr int ADDR_SLOT = NX + 1;            // scalar address arithmetic of the iteration's DMA batch
+    int sm_end[NSLOT] = {};                             // softmax steps [sm_end[s-1], sm_end[s]) run in slot s
+    int mx_end[NSLOT] = {};
+    int cost[NSLOT] = {};                               // modelled filler cost per slot (reporting)
+    int cap = 0;
+
+    // fixed work in front of the MFMA of slot s (s = NSLOT: slot 0 of the next iteration, behind the loop's back edge)
+    static constexpr int pre_cost(int s) {
+        if (s >= NSLOT) return 8 + 12 + 28;             // read-ahead + image bases + ring rotation, loop control, rescale branch
+        if (s < NX) return (s & 1) == 0 ? 8 : 0;        // K fragment read-ahead: v_xor + ds_read_b128
+        const int i = s - NX, w = i % G, wp = w - (SUM ? 2 : 0);
+        const bool is_sum = SUM && w < 2;
+        int c = 0;
+        if (!is_sum && (wp & 1) == 0) c += 8;           // V fragment (two transposed reads) or a K(t+2) fragment
+        if (i > NYB && ((i - NYB) & 1) == 1 && (i - NYB) / 2 < 2 * NJ) c += 24;         // LDS-DMA piece
+        return c;
+    }
+    // fixed work between the MFMA of slot s and the next one (the movable streams share this gap)
+    static constexpr int fixed_cost(int s) {
+        int c = pre_cost(s + 1);
+        if (s == ADDR_SLOT) c += 40;
+        if (MASKED && s == MASK_SLOT) c += 16;
+        if (s == NSLOT - 1) c += 24;                    // rescale test of tile t+1
+        return c;
+    }
+    static constexpr int step_cost(int n) {
+        int c = n < 64 ? 8 : 0;
+        const int m = n - LAG;
+        if (m >= 0) c += (SUM ? 0 : 4) + ((m & 1) ? 4 : 0);
+        return c;
+    }
+    // last slot that may hold step n: the one before the first MFMA reading the P^T word that element n - LAG belongs to
+    static constexpr int step_deadline(int n) {
+        const int m = n < LAG ? 0 : n - LAG, c = m >> 3, kk = c >> 1, z = c & 1;
+        return NX + kk * G + z - 1;
+    }
+    static constexpr int mx_cost(int u) { return u < 32 ? 4 : 28; }
+    static constexpr int mx_earliest(int u) {
+        if (MASKED) return MASK_SLOT + 1;
+        const int q = u >> 1;
+        return q < 8 ? NX / 2 + 2 : NX + 2;             // logits of key block 0 are complete half way through phase X
+    }
+    static constexpr int kMxDeadline = NSLOT - 2;       // the rescale test of the last slot reads the finished row max
+
+    constexpr bool fill(int budget) {
+        // row-max items as LATE as their deadline allows (the tail of phase Y has nothing else to do: every P^T word is due
+        // before the last 16-key step), softmax steps as EARLY as the budget allows
+        int u = NMX;
+        for (int sl = NSLOT - 1; sl >= 0; --sl) {
+            int used = fixed_cost(sl);
+            mx_end[sl] = u;
+            if (sl <= kMxDeadline)
+                while (u > 0 && mx_earliest(u - 1) <= sl && used + mx_cost(u - 1) <= budget) used += mx_cost(--u);
+            cost[sl] = used;
+        }
+        if (u > 0) return false;
+        int n = 0, over = 0;                            // over: worst overfill caused by a deadline-forced placement
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            int used = cost[sl];
+            while (n < NSTEP && (used + step_cost(n) <= budget || step_deadline(n) <= sl)) {
+                used += step_cost(n++);
+                if (used > budget && used - budget > over) over = used - budget;
+            }
+            sm_end[sl] = n;
+            cost[sl] = used;
+        }
+        cap = budget;
+        return n == NSTEP && over <= 4;
+    }
+    static constexpr W64Plan make() {
+        W64Plan pl{};
+        for (int b = 12; b <= 96; b += 2)
+            if (pl.fill(b)) break;
+        return pl;
+    }
+};
+
 template <typename T, int E> constexpr int fa_fwd_w64_lds_bytes(bool masked) {
     return 3 * (RowImg<T, E>::bytes(64) + ColImg<T, E>::bytes(64)) + (masked ? 16 + 8 * kMaxMaskTiles : 0);
 }
@@ -162,6 +272,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     constexpr bool kSum = NNOP_W64_MFMASUM != 0 && E <= 64;  // row sums on the matrix pipe (E = 128: measured 1.7 % slower)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#if NNOP_W64_STAMP
+    uint64_t stamp[8], stamp_p[2] = {0, 0};
+    stamp[0] = __builtin_amdgcn_s_memtime();
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -397,61 +512,68 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                 mxp[(i >> 1) & 3] = fmaxf(fmaxf(mxp[(i >> 1) & 3], s[kb][i]), s[kb][i + 1]);
         return half_swap_max(fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3])) * (kPre ? 1.0f : c2));
     };
-    // Rare path, before a tile is exponentiated: some row's max outgrew the reference by > kThr (or the row sees its
-    // first key) -> raise the reference; everything accumulated at the old one (O, l) is scaled exactly once.
-    // `mx`: row max of the tile in log2 units -- absolute, or (kPre) relative to the reference that was baked into the
-    // tile's logits when its QK^T ran; `sc`: that tile (kPre: re-based onto the new reference here).
-    auto rescale = [&](const float (&mx)[2], f32x16 (&sc)[2][KB], bool first) {
+    // Before a tile is exponentiated: has some row's max outgrown the reference by > kThr (or does the row see its first
+    // key)?  `mx`: row max of the tile in log2 units -- absolute, or (kPre) relative to the reference that was baked into the
+    // tile's logits when its QK^T ran.  The test runs in the LAST slot of the iteration before (the prologue for tile 0), so
+    // that an iteration opens with nothing but the branch; m2 does not change in between.
+    // `live`: the tile exists for this wave (the last iteration computes the logits of one tile too many: in plain mode a copy
+    // of the last tile, harmless; in masked mode unmasked garbage that must not reach the row max).
+    auto rescale_test = [&](const float (&mx)[2], bool live) -> bool {
         bool any = false;
-        float mabs[2];
+        const float lim = (kGeneral && !live) ? -INFINITY : INFINITY;          // scalar select
 #pragma unroll
         for (int z = 0; z < 2; ++z) {
-            const float base = (kPre && m2[z] != -INFINITY) ? m2[z] : 0.f;      // what the logits of `sc` have subtracted
-            mabs[z] = kPre ? mx[z] + base : mx[z];
-            mt[z] = fmaxf(mt[z], mabs[z]);
-            any = any || (mabs[z] > m2[z] + kThr);
+            const float base = (kPre && m2[z] != -INFINITY) ? m2[z] : 0.f;      // what the tile's logits have subtracted
+            float mabs = kPre ? mx[z] + base : mx[z];
+            if constexpr (kGeneral) mabs = fminf(mabs, lim);
+            mt[z] = fmaxf(mt[z], mabs);
+            any = any || (mabs > m2[z] + kThr);
         }
-        if (__any(any)) {
+        return __any(any);
+    };
+    // Rare path: raise the reference; everything accumulated at the old one (O, l) is scaled exactly once, and (kPre) the
+    // tile `sc` is re-based onto the new reference.
+    auto rescale = [&](const float (&mx)[2], f32x16 (&sc)[2][KB], bool first) {
 #pragma unroll
-            for (int z = 0; z < 2; ++z) {
-                const bool up = mabs[z] > m2[z] + kThr;
-                const float mn = up ? mabs[z] : m2[z];
-                const float alpha = up ? fast_exp2(m2[z] - mn) : 1.f;     // m2 = -inf -> 0 (nothing accumulated yet)
-                if (!first) {                                             // first tile: O and l are still zero
+        for (int z = 0; z < 2; ++z) {
+            const float base0 = (kPre && m2[z] != -INFINITY) ? m2[z] : 0.f;
+            const float mabs = kPre ? mx[z] + base0 : mx[z];
+            const bool up = mabs > m2[z] + kThr;
+            const float mn = up ? mabs : m2[z];
+            const float alpha = up ? fast_exp2(m2[z] - mn) : 1.f;         // m2 = -inf -> 0 (nothing accumulated yet)
+            if (!first) {                                                 // first tile: O and l are still zero
 #pragma unroll
-                    for (int eb = 0; eb < EB; ++eb) {
-                        fence_acc_result(oacc[z][eb]);
+                for (int eb = 0; eb < EB; ++eb) {
+                    fence_acc_result(oacc[z][eb]);
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) oacc[z][eb][i] *= alpha;
-                        // back in the accumulator file BEFORE the paths merge: otherwise the merged value is allocated in
-                        // arch VGPRs and the common path pays 128 v_accvgpr_read + 128 v_accvgpr_write per tile for it
-                        asm volatile("" : "+a"(oacc[z][eb]));
-                    }
-                    if constexpr (kSum) {
-                        fence_acc_result(lacc[z]);
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) lacc[z][i] *= alpha;
-                        asm volatile("" : "+a"(lacc[z]));
-                    } else {
-                        lp[z][0] *= alpha;
-                        lp[z][1] *= alpha;
-                    }
+                    for (int i = 0; i < 16; ++i) oacc[z][eb][i] *= alpha;
+                    // back in the accumulator file BEFORE the paths merge: otherwise the merged value is allocated in
+                    // arch VGPRs and the common path pays 128 v_accvgpr_read + 128 v_accvgpr_write per tile for it
+                    asm volatile("" : "+a"(oacc[z][eb]));
                 }
-                if constexpr (kPre) {
-                    const float base = m2[z] != -INFINITY ? m2[z] : 0.f;
-                    const float nbase = mn != -INFINITY ? mn : 0.f;
-                    const float shift = base - nbase;                      // logits already hold -base
+                if constexpr (kSum) {
+                    fence_acc_result(lacc[z]);
 #pragma unroll
-                    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) sc[z][kb][i] += shift;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) negm[z][i] = -nbase;
+                    for (int i = 0; i < 16; ++i) lacc[z][i] *= alpha;
+                    asm volatile("" : "+a"(lacc[z]));
+                } else {
+                    lp[z][0] *= alpha;
+                    lp[z][1] *= alpha;
                 }
-                m2[z] = mn;
             }
-            if constexpr (kPre) fence_valu_operand(negm[0], negm[1]);
+            if constexpr (kPre) {
+                const float nbase = mn != -INFINITY ? mn : 0.f;
+                const float shift = base0 - nbase;                         // logits already hold -base0
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sc[z][kb][i] += shift;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) negm[z][i] = -nbase;
+            }
+            m2[z] = mn;
         }
+        if constexpr (kPre) fence_valu_operand(negm[0], negm[1]);
     };
 
     // ---- prologue, continued: wait for the first tiles, S(0) = K(0) Q^T, its mask and row max -----------------------
@@ -471,8 +593,12 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                      :: "memory");
     }
 
+#if NNOP_W64_STAMP
+    stamp_p[0] = __builtin_amdgcn_s_memtime();               // K(0) and Q have landed
+#endif
     f32x16 sa[2][KB], sb[2][KB];                             // score tiles: current / next (roles swap every iteration)
     float mxa[2] = {-INFINITY, -INFINITY}, mxb[2] = {-INFINITY, -INFINITY};
+    bool need = false;                                       // wave-uniform: the next tile raises a reference before its softmax
     frag_t fr[RF];                                           // fragment ring
     if (n_live > 0) {
         const uint32_t ka0 = opaque(kring + k_lane);
@@ -492,7 +618,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         }
         mxa[0] = row_max(sa[0]);
         mxa[1] = row_max(sa[1]);
+        need = rescale_test(mxa, true);
     }
+#if NNOP_W64_STAMP
+    stamp_p[1] = __builtin_amdgcn_s_memtime();               // S(0), its mask and row max are done
+#endif
     // the rest of the prologue's tiles landed, every wave's pieces
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (n_live > 0) {
@@ -503,53 +633,55 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     }
 
     // ---- one iteration: softmax + PV of tile t on `sc` (row max `mxc` known) beside QK^T of tile t+1 into `sn` ------
-    auto iteration = [&](int t, f32x16 (&sc)[2][KB], const float (&mxc)[2], f32x16 (&sn)[2][KB], float (&mxn)[2]) {
-        rescale(mxc, sc, t == 0);
+    // `need`: in -- tile t must raise a reference first (rescale_test of its row max); out -- the same for tile t+1.
+    constexpr int LAG = NNOP_W64_LAG;
+    using Plan = W64Plan<E, kSum, kGeneral, NJ, LAG>;
+    auto iteration = [&](int t, bool& need_io, f32x16 (&sc)[2][KB], const float (&mxc)[2], f32x16 (&sn)[2][KB], float (&mxn)[2]) {
+        if (__builtin_expect(need_io, 0)) rescale(mxc, sc, t == 0);
         float msub[2];
 #pragma unroll
         for (int z = 0; z < 2; ++z) msub[z] = (kGeneral && m2[z] == -INFINITY) ? 0.f : m2[z];   // no key seen yet: P = 0
         const uint32_t kimg = opaque(kA + k_lane);                // K(t+1)
         const uint32_t vimg = opaque(vA + v_lane);                // V(t)
         const uint32_t kimg2 = opaque(kB + k_lane);               // K(t+2): the next iteration's first fragments
-        frag_t pf[2 * KB][2];                                     // P^T fragments of tile t: [16-key step kk][z]
-        const TileSrc ksrc = tile_src(kp, t + 3), vsrc = tile_src(vp, t + 2);   // this iteration's DMA batch
+        u32x4 pw[2 * KB][2];                                      // P^T fragments of tile t as words: [16-key step kk][z]
+        TileSrc ksrc, vsrc;                                       // this iteration's DMA batch: K(t+3), V(t+2)
 
         // softmax element n of tile t: chunk c = n / 8 = 2 kk + z, element j = n % 8 of that chunk.  Step n issues the
-        // fma + exp of element n and THEN the row-sum add (and, when it closes a chunk, the 4 converts) of element n - 1:
-        // a consumer directly behind its v_exp_f32 costs a wait state (transcendental-result hazard, s_nop); step 64
-        // only finishes element 63.
+        // exp of element n and THEN finishes element n - LAG: the row-sum add and, for an odd element, the convert of the
+        // pair it closes (one word of the P^T fragment) -- a consumer directly behind its v_exp_f32 stalls on the
+        // transcendental unit's latency.
         auto sm_elem = [&](auto nc) {
             constexpr int n = decltype(nc)::value;
-#if NNOP_W64_ABL != 3
+#if !(NNOP_W64_ABL & 4)
             if constexpr (n < 64) {
                 constexpr int c = n >> 3, j = n & 7, kk = c >> 1, z = c & 1, kb = kk >> 1, i = 8 * (kk & 1) + j;
                 float e = kPre ? fast_exp2(sc[z][kb][i]) : fast_exp2(__builtin_fmaf(sc[z][kb][i], c2, -msub[z]));
                 pin(e);
                 sc[z][kb][i] = e;
             }
-            if constexpr (n > 0) {
-                constexpr int m = n - 1, c = m >> 3, j = m & 7, kk = c >> 1, z = c & 1, kb = kk >> 1, i = 8 * (kk & 1) + j;
+#endif
+            if constexpr (n >= LAG) {
+                constexpr int m = n - LAG, c = m >> 3, j = m & 7, kk = c >> 1, z = c & 1, kb = kk >> 1, i = 8 * (kk & 1) + j;
+#if !(NNOP_W64_ABL & 4)
                 if constexpr (!kSum) {
                     lp[z][j & 1] += sc[z][kb][i];
                     pin(lp[z][j & 1]);
                 }
-                if constexpr (j == 7) {
-                    pf[kk][z] = acc_frag<T, (kk & 1)>(sc[z][kb]);
-                    pin(pf[kk][z]);
+#endif
+                if constexpr (j & 1) {
+                    typedef T t2 __attribute__((ext_vector_type(2)));
+                    const f32x2 w = {sc[z][kb][i - 1], sc[z][kb][i]};
+                    uint32_t word = __builtin_bit_cast(uint32_t, __builtin_convertvector(w, t2));
+                    pin(word);
+                    pw[kk][z][j >> 1] = word;
                 }
             }
-#else
-            if constexpr (n > 0 && ((n - 1) & 7) == 7) {
-                constexpr int c = (n - 1) >> 3, kk = c >> 1, z = c & 1, kb = kk >> 1;
-                pf[kk][z] = acc_frag<T, (kk & 1)>(sc[z][kb]);
-                pin(pf[kk][z]);
-            }
-#endif
         };
         // fragment read PF ahead of stream position f (wraps into the next iteration's K fragments)
         auto read_ahead = [&](auto fc) {
             constexpr int g = decltype(fc)::value + PF;
-#if NNOP_W64_ABL != 5
+#if !(NNOP_W64_ABL & 16)
             if constexpr (g < NKF) fr[g % RF] = read_kfrag(kimg, g);
             else if constexpr (g < NF) fr[g % RF] = read_vfrag(vimg, g - NKF);
             else fr[g % RF] = read_kfrag(kimg2, g - NF);
@@ -561,7 +693,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         float mxp[2][4];
         auto mx_item = [&](auto uc) {
             constexpr int u = decltype(uc)::value, z = u & 1, q = u >> 1;
-#if NNOP_W64_ABL != 4
+#if !(NNOP_W64_ABL & 8)
             if constexpr (q < 16) {
                 constexpr int kb = q >> 3, i0 = 2 * (q & 7);
                 // single instructions: fmaxf() on values hipcc cannot prove canonical (asm MFMA results) costs an extra
@@ -575,25 +707,20 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #endif
         };
 
-        // -------- the schedule: which softmax steps (0 .. 64) and row-max items (0 .. 33) each slot carries -------------
-        // Phase X (NX slots, QK^T of tile t+1): steps [0, NEX).  Phase Y (NY2 slots: per 16-key step kk first the two
-        // row-sum MFMAs (kSum), then the 2 EB PV MFMAs): steps [NEX, 65) on slots [0, NYE); mask of tile t+1 at slot
-        // MX0 - 1, its row-max items on slots [MX0, NY2); tile barrier at slot NYB, the DMA batch on the odd slots behind it.
-        constexpr int G = 2 * EB + (kSum ? 2 : 0);                // slots per 16-key step
-        constexpr int NY2 = 4 * G;
-        constexpr int NEX = kSum ? 40 : (E >= 128 ? 44 : 40);
-        constexpr int NYE = kSum ? (E >= 128 ? 28 : 17) : (E >= 128 ? 22 : 12);
-        constexpr int MX0 = 3, NYB = NY2 / 2;
-        // deadline: the converts of chunk c = 2 kk + z (step 8 c + 8) sit in a slot BEFORE the first MFMA that reads P^T(kk, z)
-        // (slot kk G + z).  Step s of phase Y lands in a slot <= ((s - NEX + 1) NYE - 1) / (65 - NEX).
-        static_assert(NEX >= 32 + 1, "P^T of kk = 0, 1 is complete when phase Y starts");
-        static_assert((40 + 1 - NEX <= 0) || ((40 + 1 - NEX) * NYE - 1) / (65 - NEX) < 2 * G, "chunk (kk=2, z=0)");
-        static_assert(((48 + 1 - NEX) * NYE - 1) / (65 - NEX) < 2 * G + 1, "chunk (kk=2, z=1)");
-        static_assert(((56 + 1 - NEX) * NYE - 1) / (65 - NEX) < 3 * G, "chunk (kk=3, z=0)");
-        static_assert(NYE <= 3 * G + 1, "chunk (kk=3, z=1)");
+        // -------- the schedule (W64Plan): softmax steps and row-max items per slot by issue cost -------------------------
+        constexpr Plan plan = Plan::make();
+        constexpr int G = Plan::G, NY2 = Plan::NY2, NYB = Plan::NYB;
+        static_assert(Plan::NX == NX && plan.sm_end[Plan::NSLOT - 1] == Plan::NSTEP && plan.mx_end[Plan::NSLOT - 1] == Plan::NMX, "every item placed");
         // the first fragment of K(t+2) is read ahead from the PV slot of V fragment NVF - PF: behind the tile barrier
         static_assert(((NVF - PF) / EB) * G + (kSum ? 2 : 0) + 2 * ((NVF - PF) % EB) >= NYB, "K(t+2) reads behind the barrier");
         static_assert(NYB + 4 * NJ <= NY2, "the DMA batch fits behind the barrier");
+        auto movable = [&](auto sc_) {                            // the slot's share of the two streams
+            constexpr int sl = decltype(sc_)::value;
+            constexpr int n0 = sl ? plan.sm_end[sl - 1] : 0, n1 = plan.sm_end[sl];
+            static_for<n1 - n0>([&](auto dn) { sm_elem(std::integral_constant<int, n0 + decltype(dn)::value>{}); });
+            constexpr int u0 = sl ? plan.mx_end[sl - 1] : 0, u1 = plan.mx_end[sl];
+            static_for<u1 - u0>([&](auto du) { mx_item(std::integral_constant<int, u0 + decltype(du)::value>{}); });
+        };
 
         // -------- phase X ----------------------------------------------------------------------------------------------
         static_for<NX>([&](auto ic) {
@@ -602,14 +729,15 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             if constexpr (z == 0) read_ahead(std::integral_constant<int, f>{});
             if constexpr (ks == 0) sn[z][kb] = kPre ? MM::qk_init(fr[f % RF], qf[z][ks], negm[z]) : MM::qk_first(fr[f % RF], qf[z][ks]);
             else MM::qk_acc(sn[z][kb], fr[f % RF], qf[z][ks]);
-            constexpr int n0 = i * NEX / NX, n1 = (i + 1) * NEX / NX;
-            static_for<n1 - n0>([&](auto dn) { sm_elem(std::integral_constant<int, n0 + decltype(dn)::value>{}); });
+            __builtin_amdgcn_sched_barrier(0);                    // the MFMA opens its slot: nothing of the slot's VALU work above it
+            movable(std::integral_constant<int, i>{});
             __builtin_amdgcn_sched_barrier(0);
         });
         // -------- phase Y ----------------------------------------------------------------------------------------------
-        // No explicit wait states are needed inside the loop: every P^T fragment is written (v_cvt_pk) at least one slot
+        // No explicit wait states are needed inside the loop: every P^T word is written (v_cvt_pk) at least one slot
         // (>= one MFMA issue) before the slot whose MFMA reads it, and the score tile `sn` is first read by VALU code two
-        // MFMA slots after the last MFMA that wrote it -- the slot order is pinned by the sched_barrier(0) closing each slot.
+        // MFMA slots after the last MFMA that wrote it -- the slot order is pinned by the sched_barrier(0) closing each slot;
+        // tools/audit_w64.py checks both on the generated code.
         static_for<NY2>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int kk = i / G, w = i % G;
@@ -619,41 +747,41 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             if constexpr (i == NYB) {
                 // tile barrier: this wave's DMA batch (issued behind the previous barrier) has landed; after the barrier
                 // every wave's has, and every wave is done with the ring slots the next batch overwrites
-#if NNOP_W64_ABL == 2
+#if NNOP_W64_ABL & 2
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
             }
             // the next batch -- K(t+3), V(t+2): 2 NJ pieces -- one piece per odd slot behind the barrier (an LDS-DMA
-            // instruction occupies the wave's issue for tens of cycles; a burst of 2 NJ of them idles the matrix pipe)
+            // instruction occupies the wave's issue for ~16 cycles; a burst of 2 NJ of them idles the matrix pipe)
             if constexpr (i > NYB && ((i - NYB) & 1) == 1 && (i - NYB) / 2 < 2 * NJ) {
-#if NNOP_W64_ABL != 1
+#if !(NNOP_W64_ABL & 1)
                 constexpr int d = (i - NYB) / 2;
                 if constexpr (d < NJ) issue_piece(ksrc.tb, ksrc.ragged, ksrc.rows_valid, kC, k_src, k_row, std::integral_constant<int, d>{});
                 else issue_piece(vsrc.tb, vsrc.ragged, vsrc.rows_valid, vC, v_src, v_row, std::integral_constant<int, d - NJ>{});
 #endif
             }
             if constexpr (is_sum) {
-                MM::pv_acc(lacc[z], ones, pf[kk][z]);             // ones[32 x 16] x P^T[16 x 32]: every row = sum over the 16 keys
+                MM::pv_acc(lacc[z], ones, __builtin_bit_cast(frag_t, pw[kk][z]));   // ones[32 x 16] x P^T[16 x 32]: every row = sum over the 16 keys
             } else {
                 if constexpr (z == 0) read_ahead(std::integral_constant<int, f>{});
-                MM::pv_acc(oacc[z][eb], fr[f % RF], pf[kk][z]);
+                MM::pv_acc(oacc[z][eb], fr[f % RF], __builtin_bit_cast(frag_t, pw[kk][z]));
             }
-            if constexpr (i < NYE) {
-                constexpr int n0 = NEX + i * (65 - NEX) / NYE, n1 = NEX + (i + 1) * (65 - NEX) / NYE;
-                static_for<n1 - n0>([&](auto dn) { sm_elem(std::integral_constant<int, n0 + decltype(dn)::value>{}); });
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NX + i == Plan::ADDR_SLOT) {
+                ksrc = tile_src(kp, t + 3);
+                vsrc = tile_src(vp, t + 2);
+                asm volatile("" : "+s"(ksrc.tb), "+s"(vsrc.tb));   // computed HERE (scalar arithmetic sinks to its first use otherwise)
             }
-            if constexpr (i == MX0 - 1 && kGeneral) {
+            if constexpr (NX + i == Plan::MASK_SLOT && kGeneral) {
                 if (t + 1 < n_live) {
                     const uint64_t vn = tile_valid(t + 1);
                     if (tile_needs_mask(t + 1, vn)) apply_mask(sn, t + 1, vn);
                 }
             }
-            if constexpr (i >= MX0) {
-                constexpr int u0 = (i - MX0) * 34 / (NY2 - MX0), u1 = (i - MX0 + 1) * 34 / (NY2 - MX0);
-                static_for<u1 - u0>([&](auto du) { mx_item(std::integral_constant<int, u0 + decltype(du)::value>{}); });
-            }
+            movable(std::integral_constant<int, NX + i>{});
+            if constexpr (i == NY2 - 1) need_io = rescale_test(mxn, t + 1 < n_live);
             __builtin_amdgcn_sched_barrier(0);
         });
         rotate_slots();
@@ -670,11 +798,15 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #else
     auto leave_fence = []() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); };
 #endif
+#if NNOP_W64_STAMP
+    stamp[2] = __builtin_amdgcn_s_memtime();
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+#endif
     int t = 0;
     if (n_live >= 2) {
         for (;;) {
-            iteration(t, sa, mxa, sb, mxb);
-            iteration(t + 1, sb, mxb, sa, mxa);
+            iteration(t, need, sa, mxa, sb, mxb);
+            iteration(t + 1, need, sb, mxb, sa, mxa);
             t += 2;
             if (t + 1 >= n_live) {       // the exit edge starts BEHIND the fence
                 leave_fence();
@@ -683,7 +815,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         }
     }
     if (t < n_live) {
-        iteration(t, sa, mxa, sb, mxb);
+        iteration(t, need, sa, mxa, sb, mxb);
         leave_fence();
         ++t;
     }
@@ -695,6 +827,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         rotate_slots();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if NNOP_W64_STAMP
+    stamp[4] = __builtin_amdgcn_s_memtime();
+    stamp[5] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- epilogue: normalise, store o (16-byte stores: lane halves paired with v_permlane32_swap), ms, ls ------------
 #pragma unroll
@@ -729,7 +865,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                 const u32x4 lo = {s0[0], s1[0], s0[1], s1[1]};
                 // s?[0]: vdst after the swap (lower lanes: own g; upper lanes: lower's g+1), s?[1]: src after the swap
                 // (lower lanes: upper's g; upper lanes: own g+1)
+#if NNOP_W64_NT
+                if (qi[z] < p.QL) __builtin_nontemporal_store(lo, reinterpret_cast<u32x4*>(orow + 32 * eb + 8 * g + 8 * h));
+#else
                 if (qi[z] < p.QL) *reinterpret_cast<u32x4*>(orow + 32 * eb + 8 * g + 8 * h) = lo;
+#endif
             }
         }
         if (qi[z] < p.QL && h == 0) {
@@ -744,6 +884,18 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             ((T*)p.ls)[so] = from_f32<T>(l_out);
         }
     }
+#if NNOP_W64_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[6] = __builtin_amdgcn_s_memtime();
+    stamp[7] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+        uint64_t* dbg = reinterpret_cast<uint64_t*>((T*)p.o + ((size_t)bh * p.QL + q0w) * E);
+        for (int i = 0; i < 8; ++i) dbg[i] = stamp[i];
+        dbg[8] = (uint64_t)n_tiles;
+        dbg[9] = stamp_p[0];
+        dbg[10] = stamp_p[1];
+    }
+#endif
 }
 
 }  // namespace nnop
