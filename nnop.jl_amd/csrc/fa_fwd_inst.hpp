@@ -138,7 +138,8 @@ static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
         // causal-and-short sequences stay on the 32-row kernels: -3..-20 % there), and (masked mode) the per-tile validity
         // words in LDS.  Knob kTuneFwdW64: 0 never, 1 wherever instantiated, auto = the rule below.
         const int w64 = tune_get(kTuneFwdW64);
-        const bool fits = mode != 2 && (mode == 0 || d.kl <= 64 * kMaxMaskTiles);
+        // (its LDS-DMA addresses a (batch, kv-head) tensor through a 32-bit buffer offset)
+        const bool fits = mode != 2 && (mode == 0 || d.kl <= 64 * kMaxMaskTiles) && (long long)d.kl * E * 2 < (1LL << 32);
         const bool pays = wg256 >= 256 && (E == 128 ? d.kl >= 512 : (d.causal ? d.kl >= 4096 : d.kl >= 1024));
         if (fits && (w64 == 1 || (w64 < 0 && pays))) return kFormW64;
     }

@@ -138,18 +138,34 @@ template <typename F> NNOP_DEV F load_q_frag(const void* gptr) {
     return d;
 }
 
-// one 1-KiB LDS-DMA piece: lane l copies 16 bytes from (sbase + voff) to LDS byte (lds_dst + 16 l); lds_dst wave-uniform.
-// (The instruction's immediate offset is 13-bit signed: the 4-KiB stride between a wave's pieces does not fit, so each
-// piece has its own per-lane offset register -- loop constants -- instead of per-piece scalar address arithmetic.)
-// M0 (the DMA's LDS base) is written in the same statement that uses it.  It is NOT restored: nothing else in these
-// kernels uses M0 (gfx950 DS instructions need no M0 setup; tools/audit_w64.py fails the build's test on any other M0
-// access), and the save / restore pair was 2 of the scalar instructions each DMA cost the issue-bound wave.
-NNOP_DEV void dma_piece(const char* sbase, uint32_t voff, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+// ---- LDS-DMA ---------------------------------------------------------------------------------------------------------
+// K / V tiles go HBM -> LDS with buffer_load_dwordx4 ... lds: lane l of a wave copies 16 bytes from
+//   base(V#) + soffset + voffset(lane) + imm      to LDS byte      M0 + imm + 16 l .
+// A wave owns NJ CONSECUTIVE 1-KiB pieces of a tile image, so one M0 (the image's ring slot + the wave's share) and one scalar
+// offset (the tile) serve all of them, the piece being selected by the immediate (which both addresses add): per tile and
+// tensor 2 scalar instructions + NJ loads instead of 3 scalar instructions per piece -- on a wave whose ISSUE is the bound, a
+// scalar instruction costs as much as a vector one (tools/ubench/gapcost.hip).  The image's swizzle is applied to the lane's
+// SOURCE offset (the destination is lane-linear).  The descriptor's NUM_RECORDS is the byte size of the (batch, kv-head)
+// tensor; on gfx950 the range check covers soffset + voffset + imm (measured: tools/ubench/probe_buf.hip,
+// profiles/r02/probe_buf.log), so the rows of the last tile past KL are out of range and read as zeros -- finite data
+// behind the mask -- with no per-lane clamping.
+// M0 is written in the statement of a tensor's first piece and stays for its other pieces; nothing else in these kernels uses
+// M0 (gfx950 DS instructions need no M0 setup; tools/audit_w64.py fails on any other M0 access).
+NNOP_DEV u32x4 make_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);       // stride 0: raw buffer
+    r[2] = bytes;
+    r[3] = 0x00020000u;                                                         // DATA_FORMAT = 32 (untyped dword access)
+    return r;
 }
-// same, every lane with its own 64-bit source address (ragged tiles: rows clamped into the tensor)
-NNOP_DEV void dma_piece_addr(const char* vaddr, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vaddr), "s"(lds_dst) : "memory");
+template <int J, bool FIRST> NNOP_DEV void dma_piece(u32x4 rsrc, uint32_t voff, uint32_t soff, uint32_t lds_dst) {
+    if constexpr (FIRST)
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen offset:%4 lds"
+                     :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst), "n"(J * 1024) : "memory");
+    else
+        asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" :: "v"(voff), "s"(rsrc), "s"(soff), "n"(J * 1024) : "memory");
 }
 
 // ---- the slot plan ------------------------------------------------------------------------------------------------
@@ -341,63 +357,68 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     }
 
     // ---- per-lane DMA source offsets inside a tile (the image's layout, applied to the SOURCE) -------------------
-    // piece pc = 4 j + wave covers LDS bytes [1024 pc, 1024 pc + 1024) of the tile's image; the matching source bytes
-    // are j * 4096 + (lane constant) for both images and both E (fa_fwd_w64 header).
-    uint32_t k_src, v_src;
-    int k_row, v_row;                                        // tile row this lane copies at j = 0 (rows advance 4096 / row bytes per j)
-    {
-        const int off = wave * 1024 + lane * 16;             // LDS byte inside the image, j = 0
+    // wave w copies the image bytes [NJ KiB * w, NJ KiB * (w + 1)), piece j = its j-th KiB; lane l the 16 bytes at 16 l.
+    // k_voff[j] / v_voff: source byte of that chunk inside the tile MINUS 1024 j (the load's immediate adds it back).
+    static_assert(NJ * 1024 * 4 == KBYTES && NJ <= 4, "four waves x NJ pieces = one image; the immediate is 12 bits");
+    uint32_t k_voff[NJ], v_voff;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int off = (wave * NJ + j) * 1024 + lane * 16;  // LDS byte inside the image
         const int row = off / KImg::kRowBytes, phys = (off % KImg::kRowBytes) >> 4;
-        k_row = row;
-        k_src = (uint32_t)(row * KImg::kRowBytes + ((phys ^ KImg::xor_of(row)) << 4));
-        const int blk = off >> 8, rg = blk / VImg::kEB, eb = blk % VImg::kEB, rr = (off >> 6) & 3, c4 = (off >> 4) & 3;
-        v_row = 4 * rg + rr;
-        v_src = (uint32_t)(v_row * VImg::kRowBytes + ((4 * eb + c4) << 4));
-    }
-    constexpr int ROWS_PER_J = 4096 / KImg::kRowBytes;
-    // piece j (0 .. NJ-1) of the tile at `tb` (`ragged`: its rows past KL do not exist) into the ring slot at LDS byte `slot`
-    auto issue_piece = [&](const char* tb, bool ragged, int rows_valid, uint32_t slot, uint32_t src, int row0, auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const uint32_t dst0 = slot + (uint32_t)(wave * 1024);
-        if (!ragged) {
-            dma_piece(tb, src + (uint32_t)(j * 4096), dst0 + j * 4096);
-        } else {
-            // last, partial tile: rows past KL are copied from row KL-1 (finite data; their logits are masked out)
-            const int row = row0 + j * ROWS_PER_J;
-            const int rc = row < rows_valid ? row : rows_valid - 1;
-            dma_piece_addr(tb + (size_t)rc * KImg::kRowBytes + (src - (uint32_t)(row0 * KImg::kRowBytes)), dst0 + j * 4096);
+        k_voff[j] = (uint32_t)(row * KImg::kRowBytes + ((phys ^ KImg::xor_of(row)) << 4) - j * 1024);
+        if (j == 0) {
+            // blocked V image: +1 KiB in the image = +1 KiB in the source for every j (4 blocks = 8 / 4 rows at E = 64 / 128)
+            const int blk = off >> 8, rg = blk / VImg::kEB, eb = blk % VImg::kEB, rr = (off >> 6) & 3, c4 = (off >> 4) & 3;
+            v_voff = (uint32_t)((4 * rg + rr) * VImg::kRowBytes + ((4 * eb + c4) << 4));
         }
-    };
+    }
+    static_assert((1024 / 256) % VImg::kEB == 0 && (4 * (1024 / 256 / VImg::kEB)) * VImg::kRowBytes == 1024, "V image: 1 KiB = whole row groups");
+    const uint32_t wave_off = (uint32_t)(wave * NJ * 1024);
+    const uint32_t kv_bytes = (uint32_t)p.KL * (uint32_t)KImg::kRowBytes;     // one (batch, kv-head) tensor; < 4 GiB (launcher)
+    const u32x4 krs = make_rsrc(kp, kv_bytes), vrs = make_rsrc(vp, kv_bytes);
     // Past the last tile the LAST tile is copied again (into a ring slot nobody reads any more) instead of branching
     // around the issue: a branch inside the loop body splits its basic block, and hipcc then sinks the softmax
     // arithmetic of the earlier slots below the branch, next to its first use (see pin() below).
-    struct TileSrc { const char* tb; bool ragged; int rows_valid; };
-    auto tile_src = [&](const char* gbase, int t) {
-        const int tc = t < n_tiles ? t : n_tiles - 1;
-        TileSrc r;
-        r.tb = gbase + (size_t)tc * TILE_BYTES;
-        r.ragged = kGeneral && (tc + 1) * BK > p.KL;
-        r.rows_valid = p.KL - tc * BK;
-        return r;
+    auto tile_off = [&](int t) -> uint32_t { return (uint32_t)(t < n_tiles ? t : n_tiles - 1) * (uint32_t)TILE_BYTES; };
+    // piece j of the tile at byte `soff` of the tensor behind `rs`, into the ring slot whose wave share starts at LDS byte `dst`
+    auto issue_piece = [&](u32x4 rs, uint32_t soff, uint32_t dst, uint32_t voff, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        dma_piece<j, j == 0>(rs, voff, soff, dst);
     };
     auto issue_k = [&](int t, uint32_t slot) {
-        const TileSrc ts = tile_src(kp, t);
-        static_for<NJ>([&](auto jc) { issue_piece(ts.tb, ts.ragged, ts.rows_valid, slot, k_src, k_row, jc); });
+        const uint32_t so = tile_off(t);
+        static_for<NJ>([&](auto jc) { issue_piece(krs, so, slot, k_voff[decltype(jc)::value], jc); });
     };
     auto issue_v = [&](int t, uint32_t slot) {
-        const TileSrc ts = tile_src(vp, t);
-        static_for<NJ>([&](auto jc) { issue_piece(ts.tb, ts.ragged, ts.rows_valid, slot, v_src, v_row, jc); });
+        const uint32_t so = tile_off(t);
+        static_for<NJ>([&](auto jc) { issue_piece(vrs, so, slot, v_voff, jc); });
     };
     // Ring slots (LDS byte addresses) as rotating scalars -- no t % 3 arithmetic in the loop:
     //   kA, kB, kC = slots of K(t+1), K(t+2), K(t+3) (= K(t)'s, free);   vA, vB, vC = slots of V(t), V(t+1), V(t+2) (free)
-    uint32_t kA = kring + 1 * KBYTES, kB = kring + 2 * KBYTES, kC = kring;
-    uint32_t vA = vring, vB = vring + 1 * VBYTES, vC = vring + 2 * VBYTES;
+    // Each holds slot + this wave's DMA share (wave_off): the DMA uses it as is, the fragment reads add a lane base that has
+    // wave_off subtracted.
+    uint32_t kA = kring + wave_off + 1 * KBYTES, kB = kring + wave_off + 2 * KBYTES, kC = kring + wave_off;
+    uint32_t vA = vring + wave_off, vB = vring + wave_off + 1 * VBYTES, vC = vring + wave_off + 2 * VBYTES;
+    // byte offsets (inside the tensor) of the tiles the next DMA batch copies: K(t+3), V(t+2), clamped to the last tile
+    const uint32_t last_off = (uint32_t)(n_tiles - 1) * (uint32_t)TILE_BYTES;
+    uint32_t off_k3 = tile_off(3), off_v2 = tile_off(2);
+    auto advance_offsets = [&]() {
+        off_v2 = off_k3;
+        const uint32_t nx = off_k3 + (uint32_t)TILE_BYTES;
+        off_k3 = nx < last_off ? nx : last_off;
+    };
     auto rotate_slots = [&]() {
         const uint32_t k0 = kA, v0 = vA;
         kA = kB; kB = kC; kC = k0;
         vA = vB; vB = vC; vC = v0;
     };
 
+    // ragged KL: the rows of the last tile past KL are outside the descriptor's range.  Whatever the DMA does with such a lane
+    // (zeros, or nothing), the ring must not hold non-finite garbage there -- V rows of masked keys are multiplied by P = 0.
+    if (kGeneral && (p.KL & (BK - 1)) != 0) {
+        for (int i = tid * 16; i < NS * (KBYTES + VBYTES); i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+        __syncthreads();
+    }
     // ---- prologue: K(0..2), V(0..1) in flight; Q fragments straight to registers ----------------------------------
     issue_k(0, kC);                                          // K(0) first: S(0) needs only K(0) and Q
     const float c2 = p.scale * kLog2e;
@@ -461,8 +482,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // V transposed read (ColImg): image + lane_base + compile-time offsets.
     typedef __attribute__((address_space(3))) const frag_t* lds_frag_p;
     typedef __attribute__((address_space(3))) s16x4* lds_tr_p;
-    const uint32_t k_lane = (uint32_t)(r * KImg::kRowBytes + ((KImg::xor_of(r) ^ h) << 4));
-    const uint32_t v_lane = (uint32_t)VImg::lane_base(lane);
+    const uint32_t k_lane = (uint32_t)(r * KImg::kRowBytes + ((KImg::xor_of(r) ^ h) << 4)) - wave_off;     // ring scalars include wave_off
+    const uint32_t v_lane = (uint32_t)VImg::lane_base(lane) - wave_off;
     auto read_kfrag = [&](uint32_t ka, int f) -> frag_t {          // ka = image address + k_lane
         const int kb = f / KS, ks = f % KS;
         return *(lds_frag_p)(uintptr_t)((ka ^ (uint32_t)(ks << 5)) + (uint32_t)(kb * 32 * KImg::kRowBytes));
@@ -518,7 +539,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // that an iteration opens with nothing but the branch; m2 does not change in between.
     // `live`: the tile exists for this wave (the last iteration computes the logits of one tile too many: in plain mode a copy
     // of the last tile, harmless; in masked mode unmasked garbage that must not reach the row max).
-    auto rescale_test = [&](const float (&mx)[2], bool live) -> bool {
+    auto rescale_test = [&](const float (&mx)[2], bool live) -> int {
         bool any = false;
         const float lim = (kGeneral && !live) ? -INFINITY : INFINITY;          // scalar select
 #pragma unroll
@@ -529,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             mt[z] = fmaxf(mt[z], mabs);
             any = any || (mabs > m2[z] + kThr);
         }
-        return __any(any);
+        return __builtin_amdgcn_ballot_w64(any) != 0 ? 1 : 0;    // wave-uniform, a scalar register across the loop's back edge
     };
     // Rare path: raise the reference; everything accumulated at the old one (O, l) is scaled exactly once, and (kPre) the
     // tile `sc` is re-based onto the new reference.
@@ -598,10 +619,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #endif
     f32x16 sa[2][KB], sb[2][KB];                             // score tiles: current / next (roles swap every iteration)
     float mxa[2] = {-INFINITY, -INFINITY}, mxb[2] = {-INFINITY, -INFINITY};
-    bool need = false;                                       // wave-uniform: the next tile raises a reference before its softmax
+    int need = 0;                                            // wave-uniform: the next tile raises a reference before its softmax
     frag_t fr[RF];                                           // fragment ring
     if (n_live > 0) {
-        const uint32_t ka0 = opaque(kring + k_lane);
+        const uint32_t ka0 = opaque(kC + k_lane);
 #pragma unroll
         for (int f = 0; f < NKF; ++f) {
             const frag_t a = read_kfrag(ka0, f);
@@ -636,8 +657,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // `need`: in -- tile t must raise a reference first (rescale_test of its row max); out -- the same for tile t+1.
     constexpr int LAG = NNOP_W64_LAG;
     using Plan = W64Plan<E, kSum, kGeneral, NJ, LAG>;
-    auto iteration = [&](int t, bool& need_io, f32x16 (&sc)[2][KB], const float (&mxc)[2], f32x16 (&sn)[2][KB], float (&mxn)[2]) {
-        if (__builtin_expect(need_io, 0)) rescale(mxc, sc, t == 0);
+    auto iteration = [&](int t, int& need_io, f32x16 (&sc)[2][KB], const float (&mxc)[2], f32x16 (&sn)[2][KB], float (&mxn)[2]) {
+        if (__builtin_expect(need_io != 0, 0)) rescale(mxc, sc, t == 0);
         float msub[2];
 #pragma unroll
         for (int z = 0; z < 2; ++z) msub[z] = (kGeneral && m2[z] == -INFINITY) ? 0.f : m2[z];   // no key seen yet: P = 0
@@ -645,7 +666,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         const uint32_t vimg = opaque(vA + v_lane);                // V(t)
         const uint32_t kimg2 = opaque(kB + k_lane);               // K(t+2): the next iteration's first fragments
         u32x4 pw[2 * KB][2];                                      // P^T fragments of tile t as words: [16-key step kk][z]
-        TileSrc ksrc, vsrc;                                       // this iteration's DMA batch: K(t+3), V(t+2)
+        uint32_t ksoff = 0, vsoff = 0, kdst = 0, vdst = 0;       // this iteration's DMA batch: K(t+3), V(t+2)
 
         // softmax element n of tile t: chunk c = n / 8 = 2 kk + z, element j = n % 8 of that chunk.  Step n issues the
         // exp of element n and THEN finishes element n - LAG: the row-sum add and, for an odd element, the convert of the
@@ -758,8 +779,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             if constexpr (i > NYB && ((i - NYB) & 1) == 1 && (i - NYB) / 2 < 2 * NJ) {
 #if !(NNOP_W64_ABL & 1)
                 constexpr int d = (i - NYB) / 2;
-                if constexpr (d < NJ) issue_piece(ksrc.tb, ksrc.ragged, ksrc.rows_valid, kC, k_src, k_row, std::integral_constant<int, d>{});
-                else issue_piece(vsrc.tb, vsrc.ragged, vsrc.rows_valid, vC, v_src, v_row, std::integral_constant<int, d - NJ>{});
+                if constexpr (d < NJ) issue_piece(krs, ksoff, kdst, k_voff[d < NJ ? d : 0], std::integral_constant<int, d>{});
+                else issue_piece(vrs, vsoff, vdst, v_voff, std::integral_constant<int, d - NJ>{});
 #endif
             }
             if constexpr (is_sum) {
@@ -770,9 +791,12 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NX + i == Plan::ADDR_SLOT) {
-                ksrc = tile_src(kp, t + 3);
-                vsrc = tile_src(vp, t + 2);
-                asm volatile("" : "+s"(ksrc.tb), "+s"(vsrc.tb));   // computed HERE (scalar arithmetic sinks to its first use otherwise)
+                ksoff = off_k3;
+                vsoff = off_v2;
+                kdst = kC;
+                vdst = vC;
+                advance_offsets();
+                asm volatile("" : "+s"(off_k3));                  // computed HERE (scalar arithmetic sinks to its first use otherwise)
             }
             if constexpr (NX + i == Plan::MASK_SLOT && kGeneral) {
                 if (t + 1 < n_live) {

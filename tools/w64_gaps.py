@@ -14,12 +14,21 @@ from audit_w64 import compile_asm, kernels
 TRANS = ("v_exp_f32", "v_rcp_f32", "v_log_f32", "v_rsq_f32", "v_sqrt_f32")
 
 
+# calibrated on tools/ubench/gapcost.hip (profiles/r02/gapcost.log): marginal cycles of one more instruction in a gap that is already full
+COST = dict(mfma=8, trans=8, valu=4, salu=6, nop=2, wait=2, barrier=6, ds128=12, dstr=10, dma=40)
+
+
 def cost(op, args):
-    if op.startswith("v_mfma"): return 8
-    if op.startswith(TRANS): return 8
-    if op == "s_nop": return max(4, int(args[0]) + 1)
-    if op.startswith("s_waitcnt") or op == "s_barrier": return 0
-    return 4
+    if op.startswith("v_mfma"): return COST["mfma"]
+    if op.startswith(TRANS): return COST["trans"]
+    if op == "s_nop": return COST["nop"] * (int(args[0]) + 1)
+    if op.startswith("s_waitcnt"): return COST["wait"]
+    if op == "s_barrier": return COST["barrier"]
+    if op.startswith("ds_read_b128"): return COST["ds128"]
+    if op.startswith("ds_"): return COST["dstr"]
+    if op.startswith("global_load_lds"): return COST["dma"]
+    if op.startswith("s_"): return COST["salu"]
+    return COST["valu"]
 
 
 def main():
