@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-bwd", action="store_true", help="skip the (untimed-region) fwd+bwd leg")
     ap.add_argument("--gather", action="store_true", help="also time the optional all-gather of O (N>1)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--settle-ms", type=float, default=400.0,
+                    help="untimed: run the step back to back for this long BEFORE the W warm-up steps, so that the timed K steps "
+                         "see the sustained (power-managed) clock instead of the first milliseconds after idle; 0 = off")
     return ap.parse_args()
 
 
@@ -177,6 +180,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def settle(fn):
+        # A launch of the headline workload lasts ~70 us: K = 20 steps straight after idle measure the DVFS ramp, not the kernel.
+        t_end = time.perf_counter() + args.settle_ms * 1e-3
+        while args.settle_ms > 0 and time.perf_counter() < t_end:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+
+    settle(step)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -217,6 +229,7 @@ def main():
         fb = lambda: (pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal, kpad_mask=kpad),
                       pkg.fa_bwd_into(dq, dk, dv, None, ws, do, o, ms, ls, q, k, v, causal=causal, kpad_mask=kpad))
         nb = max(args.steps // 4, 5)
+        settle(fb)
         for _ in range(max(args.warmup // 4, 2)):
             fb()
         barrier()
@@ -282,7 +295,7 @@ def main():
         "metric": "attention TFLOPs/s + GB/s (fwd, fwd+bwd) at E=64,L=4096,H=4,B=4" if args.config == "c2" else
                   f"attention TFLOPs/s + GB/s (fwd, fwd+bwd), workload {args.config}",
         "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "warmup": args.warmup, "settle_ms": args.settle_ms, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": dtn, "data": "synthetic",
         "config": {"workload": f"{args.config.upper()}: {dtn} {'causal' if causal else 'non-causal'} "
                                f"flash_attention forward, E={E} L={L} QH={QH} KH={KH} B={B} " + ("global" if strong else "per GPU"),
