@@ -111,6 +111,16 @@ int nnop_fa_fwd(const nnop_fa_desc* d,
 size_t nnop_fa_bwd_workspace_bytes(const nnop_fa_desc* d);
 
 /*
+ * The same for a call WITH a pair bias (ABI version 5).  `pair` / `dpair` are [B][KL][QL][QH] with the head fastest
+ * (src/attention.jl:62): per head their elements are QH apart, which a (batch, head) kernel can only touch one element per
+ * lane.  Given this much scratch -- the small workspace + three head-major copies of the bias-sized tensor, padded to
+ * multiples of 64 -- nnop_fa_bwd re-packs the bias once, runs its kernels on 16-byte accesses and unpacks dpair at the end
+ * (bf16 E=64 L=2048 H=4 B=4: see DESIGN.md).  A caller that passes only nnop_fa_bwd_workspace_bytes() gets the same results
+ * from the direct (slow) path; nnop_fa_bwd picks by `workspace_bytes`.  Returns 0 for an invalid descriptor.
+ */
+size_t nnop_fa_bwd_workspace_bytes_pair(const nnop_fa_desc* d);
+
+/*
  * Backward: contract of NNop.∇flash_attention (src/attention_bwd.jl:199-275) + kernels
  * _flash_attention_bwd_preprocess! (:163-197) and _flash_attention_bwd! (:1-161).
  * Writes dq, dk, dv (fully overwritten -- the caller need not zero them) and, when `pair`
@@ -212,7 +222,7 @@ int nnop_shared_memory(int device, uint64_t* bytes);
 const char* nnop_strerror(int status);
 
 /* ABI version of this header: bumped on any incompatible change. */
-#define NNOP_HIP_ABI_VERSION 4
+#define NNOP_HIP_ABI_VERSION 5
 int nnop_abi_version(void);
 
 #ifdef __cplusplus

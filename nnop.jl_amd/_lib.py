@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NNOP_LIB_PATH") or os.path.join(_HERE, "lib", "libnnop_hip.so")
 
 # NNOP_HIP_ABI_VERSION of the header this binding was written against; load() refuses another library
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # nnop_dtype (include/nnop_hip.h)
 NNOP_F32, NNOP_F16, NNOP_BF16 = 0, 1, 2
@@ -35,6 +35,7 @@ NNOP_ERR_HIP = -10
 EXPORTED_SYMBOLS = (
     "nnop_fa_fwd",
     "nnop_fa_bwd_workspace_bytes",
+    "nnop_fa_bwd_workspace_bytes_pair",
     "nnop_fa_bwd",
     "nnop_llama_rope",
     "nnop_online_softmax",
@@ -108,6 +109,8 @@ def load():
     lib.nnop_fa_fwd.argtypes = [C.POINTER(FaDesc), vp, vp, vp, vp, vp, vp, vp, u8p, vp]
     lib.nnop_fa_bwd_workspace_bytes.restype = C.c_size_t
     lib.nnop_fa_bwd_workspace_bytes.argtypes = [C.POINTER(FaDesc)]
+    lib.nnop_fa_bwd_workspace_bytes_pair.restype = C.c_size_t
+    lib.nnop_fa_bwd_workspace_bytes_pair.argtypes = [C.POINTER(FaDesc)]
     lib.nnop_fa_bwd.restype = C.c_int
     lib.nnop_fa_bwd.argtypes = [C.POINTER(FaDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                 u8p, vp, C.c_size_t, vp]

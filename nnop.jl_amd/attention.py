@@ -134,8 +134,12 @@ def shared_memory(device_id: int = 0) -> int:
     return int(out.value)
 
 
-def bwd_workspace_bytes(q, k, v, *, causal: bool) -> int:
-    return int(_lib.load().nnop_fa_bwd_workspace_bytes(C.byref(_desc(q, k, v, causal))))
+def bwd_workspace_bytes(q, k, v, *, causal: bool, pair: bool = False) -> int:
+    """``nnop_fa_bwd_workspace_bytes``; ``pair=True``: ``nnop_fa_bwd_workspace_bytes_pair`` -- the scratch with which the
+    backward of a call WITH a pair bias runs on 16-byte accesses (the small size still works, through the slow direct path)."""
+    lib = _lib.load()
+    f = lib.nnop_fa_bwd_workspace_bytes_pair if pair else lib.nnop_fa_bwd_workspace_bytes
+    return int(f(C.byref(_desc(q, k, v, causal))))
 
 
 def fa_fwd_into(o, ms, ls, q, k, v, pair=None, *, causal: bool, kpad_mask=None):
@@ -212,6 +216,8 @@ def grad_flash_attention(dO, o, ms, ls, q, k, v, pair=None, *, causal: bool, kpa
         dv = torch.empty_like(v)
         dpair = torch.empty_like(pair) if pair is not None else None
         nbytes = int(lib.nnop_fa_bwd_workspace_bytes(C.byref(d)))
+        if nbytes != 0 and pair is not None:
+            nbytes = max(nbytes, int(lib.nnop_fa_bwd_workspace_bytes_pair(C.byref(d))))    # staged pair-bias path
         if nbytes == 0:
             st = lib.nnop_fa_bwd(C.byref(d), *([C.c_void_p(0)] * 13), C.c_void_p(0), 0, C.c_void_p(0))
             _raise_status(st, q, k, v)

@@ -33,6 +33,7 @@
 #pragma once
 #include <type_traits>
 #include "fa_common.hpp"
+#include "pair_tile.hpp"
 
 namespace nnop {
 
@@ -46,6 +47,10 @@ struct BwdParams {
     int   n_blk;     // blocks along the workgroup's sequence axis
     int   n_wg;
     float scale;
+    // MODE 3 (pair_tile.hpp): head-major scratch copies of the pair bias and the dS scratch, zero-padded to QLp x KLp
+    const void *pair_a, *pair_b;
+    void* dpair_s;
+    int   QLp, KLp;
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -140,7 +145,8 @@ constexpr int fa_bwd_dkdv_lds_bytes() {
 template <typename T, int E, int NW, int BQ, int MODE>
 __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void fa_bwd_dkdv_kernel(const BwdParams p) {
     constexpr bool kGeneral = MODE != 0;
-    constexpr bool kPair = MODE == 2;
+    constexpr bool kPair = MODE >= 2;
+    constexpr bool kStaged = MODE == 3;          // pair bias through head-major scratch + LDS tiles (pair_tile.hpp)
     using frag_t = typename Elem<T>::frag;
     using Imgs = BwdImgs<T, E>;
     using Row = typename Imgs::Row;
@@ -290,6 +296,12 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             if (q0 >= p.QL) continue;
             if (kGeneral && p.causal && q0 + 31 < kw0) continue;       // block entirely above the diagonal
 
+            typename PairTile<T>::Regs pregs;                              // kStaged: the bias tile, fetched ahead of the MFMAs
+            if constexpr (kStaged) {
+                // rows = queries q0 .. q0+31 (register axis), columns = this wave's 32 keys (lane axis): copy B
+                const int kcol = kw0 < p.KLp - 32 ? kw0 : p.KLp - 32;     // a wave past KL stays inside the scratch
+                pregs = PairTile<T>::fetch((const T*)p.pair_b + (((size_t)b * p.QH + qh) * p.QLp + q0) * p.KLp + kcol, (size_t)p.KLp, lane);
+            }
             f32x16 s, dp;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -316,7 +328,10 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             // (dpair is written by the dQ kernel, where the lane axis is the tensor's contiguous direction)
             const T* pbase = nullptr;
             int qmax = 0;
-            if constexpr (kPair) {
+            float pv[16];                                                  // kStaged: this lane's 16 bias values
+            if constexpr (kStaged) {
+                PairTile<T>::unpack(pregs, smem + fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>() + wave * PairTile<T>::kBytes, lane, pv);
+            } else if constexpr (kPair) {
                 pbase = (const T*)p.pair + (((size_t)b * p.KL + key_c) * p.QL + q0) * p.QH + qh;
                 qmax = p.QL - 1 - q0;                                      // last in-range local query row
             }
@@ -329,7 +344,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                 for (int i = 0; i < 16; ++i) {
                     float x = s[i] * c2;
                     const int lrow = acc_row(i, h);
-                    if constexpr (kPair) {
+                    if constexpr (kStaged) {
+                        x += pv[i] * kLog2e;
+                    } else if constexpr (kPair) {
                         const int lr = lrow < qmax ? lrow : qmax;            // clamped: always inside the tensor
                         x += to_f32(pbase[lr * p.QH]) * kLog2e;
                     }
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                     ds[i] = pr * dp[i];
                 }
             };
-            if constexpr (kPair) {
+            if constexpr (kPair && !kStaged) {
                 p_ds(std::true_type{});                       // one body: the pair gather is not duplicated
             } else if constexpr (kGeneral) {
                 if (diag) p_ds(std::true_type{});
@@ -409,7 +426,8 @@ constexpr int fa_bwd_dq_lds_bytes() {
 template <typename T, int E, int NW, int BK, int MODE>
 __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void fa_bwd_dq_kernel(const BwdParams p) {
     constexpr bool kGeneral = MODE != 0;
-    constexpr bool kPair = MODE == 2;
+    constexpr bool kPair = MODE >= 2;
+    constexpr bool kStaged = MODE == 3;          // pair bias / dS through head-major scratch + LDS tiles (pair_tile.hpp)
     using frag_t = typename Elem<T>::frag;
     using Imgs = BwdImgs<T, E>;
     using Row = typename Imgs::Row;
@@ -548,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             }
             if (valid == 0ull) skip = true;
             need_mask = (valid != ((BK < 64) ? ((1ull << BK) - 1ull) : ~0ull)) ||
-                        (p.causal && k0 + BK - 1 > q0w) || kPair;
+                        (p.causal && k0 + BK - 1 > q0w) || (kPair && !kStaged);
         }
 
         if (!skip) {
@@ -557,6 +575,12 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             const char* vrow = cur + KIMG;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
+                typename PairTile<T>::Regs pregs;                          // kStaged: the bias tile, fetched ahead of the MFMAs
+                const int qcol = q0w < p.QLp - 32 ? q0w : p.QLp - 32;     // a wave past QL stays inside the scratch
+                if constexpr (kStaged) {
+                    // rows = keys k0 + 32 kb .. (register axis), columns = this wave's 32 queries (lane axis): copy A
+                    pregs = PairTile<T>::fetch((const T*)p.pair_a + (((size_t)b * p.QH + qh) * p.KLp + k0 + 32 * kb) * p.QLp + qcol, (size_t)p.QLp, lane);
+                }
                 f32x16 s, dp;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { s[i] = nlq; dp[i] = ndl; }
@@ -576,7 +600,12 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                 const T* pbase = nullptr;
                 T* dpbase = nullptr;
                 int kstride = 0, kmax = 0;
-                if constexpr (kPair) {
+                float pv[16];                                              // kStaged: this lane's 16 bias values
+                char* ptile = nullptr;
+                if constexpr (kStaged) {
+                    ptile = smem + fa_bwd_dq_lds_bytes<T, E, NW, BK>() + wave * PairTile<T>::kBytes;
+                    PairTile<T>::unpack(pregs, ptile, lane, pv);
+                } else if constexpr (kPair) {
                     kstride = p.QL * p.QH;
                     kmax = p.KL - 1 - k0;
                     const size_t po = (((size_t)b * p.KL + k0) * p.QL + qi_c) * p.QH + qh;
@@ -589,12 +618,13 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         float x = s[i] * c2;
+                        if constexpr (kStaged) x += pv[i] * kLog2e;
                         bool ok = true;
                         if constexpr (decltype(masked)::value) {
                             const int lr = (i & 3) + 8 * (i >> 2);
                             ok = (w >> lr) & 1u;
                             if (p.causal) ok = ok && (lr <= lim);
-                            if constexpr (kPair) {
+                            if constexpr (kPair && !kStaged) {
                                 int kl = 32 * kb + lr + 4 * h;
                                 kl = kl < kmax ? kl : kmax;
                                 x += to_f32(pbase[kl * kstride]) * kLog2e;
@@ -603,20 +633,30 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                         float pr = fast_exp2(x);
                         if constexpr (decltype(masked)::value) pr = ok ? pr : 0.f;
                         ds[i] = pr * dp[i];
-                        if constexpr (kPair) {
+                        if constexpr (kPair && !kStaged) {
                             // dpair = dS (the reference's dS / scale, src/attention_bwd.jl:123-132); lanes = consecutive queries
                             const int klr = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
                             if (klr <= kmax && qi < p.QL) dpbase[klr * kstride] = from_f32<T>(ds[i]);
                         }
                     }
                 };
-                if constexpr (kPair) {
+                if constexpr (kPair && !kStaged) {
                     p_ds(std::true_type{});                   // need_mask is always set with a pair bias
                 } else if constexpr (kGeneral) {
                     if (need_mask) p_ds(std::true_type{});
                     else p_ds(std::false_type{});
                 } else {
                     p_ds(std::false_type{});
+                }
+                if constexpr (kStaged) {
+                    // dpair = dS (the reference's dS / scale, src/attention_bwd.jl:123-132) into the scratch matrix of this
+                    // (batch, head); masked elements are exact zeros, tiles never visited are zero-filled by the unpack kernel
+                    if (q0w < p.QL) {
+                        T* g = PairTile<T>::kStoreLaneMajor
+                                   ? (T*)p.dpair_s + (((size_t)b * p.QH + qh) * p.QLp + q0w) * p.KLp + k0 + 32 * kb
+                                   : (T*)p.dpair_s + (((size_t)b * p.QH + qh) * p.KLp + k0 + 32 * kb) * p.QLp + q0w;
+                        PairTile<T>::store(g, PairTile<T>::kStoreLaneMajor ? (size_t)p.KLp : (size_t)p.QLp, ptile, lane, ds);
+                    }
                 }
                 const frag_t d0 = acc_frag<T, 0>(ds), d1 = acc_frag<T, 1>(ds);
 #pragma unroll

@@ -23,7 +23,7 @@ template <typename T, int E> struct BwdCfg {
 
 template <typename T, int E, int NW, int BQ, int MODE>
 static int launch_dkdv(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
-    constexpr int lds = fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>();
+    constexpr int lds = fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>() + (MODE == 3 ? NW * PairTile<T>::kBytes : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = fa_bwd_dkdv_kernel<T, E, NW, BQ, MODE>;
     static unsigned long long lds_done = 0;
@@ -39,7 +39,7 @@ static int launch_dkdv(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s)
 
 template <typename T, int E, int NW, int BK, int MODE>
 static int launch_dq(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
-    constexpr int lds = fa_bwd_dq_lds_bytes<T, E, NW, BK>();
+    constexpr int lds = fa_bwd_dq_lds_bytes<T, E, NW, BK>() + (MODE == 3 ? NW * PairTile<T>::kBytes : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = fa_bwd_dq_kernel<T, E, NW, BK, MODE>;
     static unsigned long long lds_done = 0;
@@ -67,6 +67,19 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     p.causal = d.causal ? 1 : 0;
     p.scale = (float)(1.0 / sqrt((double)E));
     p.n_blk = 0; p.n_wg = 0;
+    p.pair_a = p.pair_b = nullptr; p.dpair_s = nullptr;
+    p.QLp = pair_pad(d.ql); p.KLp = pair_pad(d.kl);
+    if constexpr (MODE == 3) {
+        // scratch behind the two row vectors: copy A, copy B, dS (bwd_workspace_bytes_pair)
+        const size_t base = (bwd_workspace_bytes(d) + 255) & ~(size_t)255;
+        const size_t one = (pair_scratch_elems(d) * sizeof(T) + 255) & ~(size_t)255;
+        char* w = (char*)a.workspace + base;
+        p.pair_a = w; p.pair_b = w + one; p.dpair_s = w + 2 * one;
+        const long long nblk = (long long)d.batch * (p.KLp / 32) * (p.QLp / 32);
+        if (nblk > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+        PairPackParams pp{a.pair, (void*)p.pair_a, (void*)p.pair_b, d.ql, d.kl, d.qh, d.batch, p.QLp, p.KLp, d.causal ? 1 : 0};
+        hipLaunchKernelGGL((pair_pack_kernel<T>), dim3((unsigned)nblk), dim3(256), 1024 * d.qh * sizeof(T), s, pp);
+    }
 
     // 1. preprocess
     {
@@ -75,8 +88,8 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         if (grid > 0x7fffffffLL) return NNOP_ERR_SHAPE;
         hipLaunchKernelGGL((fa_bwd_pre_kernel<T, E>), dim3((unsigned)grid), dim3(256), 0, s, p, n_rows);
     }
-    // 2. dpair is written only where a (query, key) pair is visited: zero it first
-    if (p.dpair) {
+    // 2. dpair is written only where a (query, key) pair is visited: zero it first (MODE 3: the unpack kernel writes all of it)
+    if (p.dpair && MODE != 3) {
         const size_t bytes = (size_t)d.batch * d.kl * d.ql * d.qh * sizeof(T);
         if (hipMemsetAsync(p.dpair, 0, bytes, s) != hipSuccess) { (void)hipGetLastError(); return NNOP_ERR_HIP; }
     }
@@ -104,12 +117,23 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         if (!done) st = launch_dq<T, E, C::NW_Q, C::BK, MODE>(d, p, s);
         if (st != NNOP_OK) return st;
     }
+    if constexpr (MODE == 3) {
+        const long long nblk = (long long)d.batch * (p.KLp / 32) * (p.QLp / 32);
+        PairUnpackParams up{a.dpair, p.dpair_s, a.kpad, d.ql, d.kl, d.qh, d.batch, p.QLp, p.KLp, d.causal ? 1 : 0,
+                            PairTile<T>::kStoreLaneMajor ? 1 : 0};
+        hipLaunchKernelGGL((dpair_unpack_kernel<T>), dim3((unsigned)nblk), dim3(256), 1024 * d.qh * sizeof(T), s, up);
+    }
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
 template <typename T, int E>
 static int launch_bwd_e(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
-    if (a.pair) return launch_bwd_cfg<T, E, 2>(d, a, s);
+    if (a.pair) {
+        // staged pair path when the caller brought the scratch for it (nnop_fa_bwd_workspace_bytes_pair)
+        if (pair_staged_ok(d) && a.workspace_bytes >= bwd_workspace_bytes_pair(d) && bwd_workspace_bytes_pair(d) > bwd_workspace_bytes(d))
+            return launch_bwd_cfg<T, E, 3>(d, a, s);
+        return launch_bwd_cfg<T, E, 2>(d, a, s);
+    }
     if (d.causal || a.kpad) return launch_bwd_cfg<T, E, 1>(d, a, s);
     return launch_bwd_cfg<T, E, 0>(d, a, s);
 }

@@ -19,6 +19,7 @@ struct BwdArgs {
     const void *d_o, *o, *ms, *ls, *q, *k, *v, *pair;
     const uint8_t* kpad;
     void* workspace;
+    size_t workspace_bytes;
 };
 
 // One per dtype (fa_fwd_{f32,f16,bf16}.hip).  Return an nnop_status.
@@ -53,6 +54,23 @@ inline bool emb_supported(int e) { return e == 16 || e == 32 || e == 64 || e == 
 // bytes of backward scratch: two fp32 per query row (folded log-sum-exp, delta), [2][B][QH][QL]
 inline size_t bwd_workspace_bytes(const nnop_fa_desc& d) {
     return 2 * (size_t)d.batch * d.qh * d.ql * sizeof(float);
+}
+// With a pair bias: the same + three head-major scratch matrices (two copies of the bias, one dS), each
+// [B][QH][pad64(KL)][pad64(QL)] elements, 256-byte aligned (pair_tile.hpp).  0 when the staged path does not apply
+// (the pack kernel's LDS block holds 32 x 32 x QH elements).
+inline size_t pair_scratch_elems(const nnop_fa_desc& d) {
+    return (size_t)d.batch * d.qh * (size_t)((d.kl + 63) & ~63) * (size_t)((d.ql + 63) & ~63);
+}
+inline bool pair_staged_ok(const nnop_fa_desc& d) {
+    const size_t es = d.dtype == NNOP_F32 ? 4 : 2;
+    return (size_t)d.qh * 1024 * es <= 64 * 1024;
+}
+inline size_t bwd_workspace_bytes_pair(const nnop_fa_desc& d) {
+    const size_t base = (bwd_workspace_bytes(d) + 255) & ~(size_t)255;
+    if (!pair_staged_ok(d)) return bwd_workspace_bytes(d);
+    const size_t es = d.dtype == NNOP_F32 ? 4 : 2;
+    const size_t one = (pair_scratch_elems(d) * es + 255) & ~(size_t)255;
+    return base + 3 * one;
 }
 
 

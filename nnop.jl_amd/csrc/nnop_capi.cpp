@@ -209,6 +209,10 @@ size_t nnop_fa_bwd_workspace_bytes(const nnop_fa_desc* d) {
     if (check_desc(d) != NNOP_OK) return 0;
     return bwd_workspace_bytes(*d);
 }
+size_t nnop_fa_bwd_workspace_bytes_pair(const nnop_fa_desc* d) {
+    if (check_desc(d) != NNOP_OK || check_pair(d) != NNOP_OK) return 0;
+    return bwd_workspace_bytes_pair(*d);
+}
 
 int nnop_fa_bwd(const nnop_fa_desc* d, void* dq, void* dk, void* dv, void* dpair, const void* d_o,
                 const void* o, const void* ms, const void* ls, const void* q, const void* k,
@@ -220,7 +224,7 @@ int nnop_fa_bwd(const nnop_fa_desc* d, void* dq, void* dk, void* dv, void* dpair
     if (pair && !dpair) return NNOP_ERR_NULL;
     if (pair && check_pair(d) != NNOP_OK) return NNOP_ERR_SHAPE;
     if (workspace_bytes < bwd_workspace_bytes(*d)) return NNOP_ERR_WORKSPACE;
-    BwdArgs a{dq, dk, dv, dpair, d_o, o, ms, ls, q, k, v, pair, kpad_mask, workspace};
+    BwdArgs a{dq, dk, dv, dpair, d_o, o, ms, ls, q, k, v, pair, kpad_mask, workspace, workspace_bytes};
     hipStream_t s = (hipStream_t)stream;
     switch (d->dtype) {
         case NNOP_F32:  return launch_bwd<float>(*d, a, s);

@@ -107,6 +107,10 @@ function NNop.∇flash_attention(
 ) where T <: HipFloat
     d = Ref(desc(q, k, v, causal))
     nbytes = ccall((:nnop_fa_bwd_workspace_bytes, libnnop()), Csize_t, (Ptr{FaDesc},), d)
+    if nbytes != 0 && pair !== nothing
+        # scratch for the head-major copies of the bias: the backward then runs on 16-byte accesses (include/nnop_hip.h)
+        nbytes = max(nbytes, ccall((:nnop_fa_bwd_workspace_bytes_pair, libnnop()), Csize_t, (Ptr{FaDesc},), d))
+    end
     if nbytes == 0
         # invalid descriptor (the same four checks as the forward, src/attention_bwd.jl:210-213): a call with NULL
         # tensors returns the status of the failed check before it looks at any pointer

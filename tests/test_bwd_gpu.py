@@ -70,6 +70,35 @@ def test_pair_and_dpair(pkg, dev, dt, causal, pad, E):
     check_bwd(pkg, d, causal, dt)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("causal,pad", [(False, None), (True, "lens"), (False, "random")])
+@pytest.mark.parametrize("E,QH,KH,QL,KL", [(64, 4, 4, 300, 300), (32, 6, 2, 257, 190), (128, 2, 1, 100, 333), (16, 3, 3, 64, 64)])
+def test_pair_backward_staged_and_direct_paths(pkg, dev, dt, causal, pad, E, QH, KH, QL, KL):
+    """The backward of a call with a pair bias has two paths behind one entry point: with the scratch of
+    nnop_fa_bwd_workspace_bytes_pair it re-packs the bias head-major and works on 16-byte accesses (csrc/pair_tile.hpp), with the
+    small workspace it touches pair / dpair element-wise.  Both against the oracle, and dpair of the two bitwise equal (the same
+    products in the same order; only the route of the bias and of dS differs)."""
+    d = make_inputs(17, 2, QH, KH, QL, KL, E, dt, dev, pair=True, pad=pad)
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], d["pair"], causal=causal, kpad_mask=d["mask"])
+    small = pkg.bwd_workspace_bytes(d["q"], d["k"], d["v"], causal=causal)
+    big = pkg.bwd_workspace_bytes(d["q"], d["k"], d["v"], causal=causal, pair=True)
+    assert big > small
+    outs = []
+    for nbytes in (small, big):
+        dq, dk, dv, dp = (torch.full_like(d[n], float("nan")) for n in ("q", "k", "v", "pair"))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        pkg.fa_bwd_into(dq, dk, dv, dp, ws, d["do"], o, ms, ls, d["q"], d["k"], d["v"], d["pair"], causal=causal, kpad_mask=d["mask"])
+        torch.cuda.synchronize()
+        outs.append((dq, dk, dv, dp))
+    rq, rk, rv, rp = oracle_bwd(d, causal)
+    for dq, dk, dv, dp in outs:
+        assert_close("dq", dq, rq, dt, kind="grad")
+        assert_close("dk", dk, rk, dt, kind="grad")
+        assert_close("dv", dv, rv, dt, kind="grad")
+        assert_close("dpair", dp, rp, dt, kind="grad")
+    assert torch.equal(outs[0][3], outs[1][3]), "dpair differs between the direct and the staged path"
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_rrule_through_autograd(pkg, dev, dt):
     """src/attention_crc.jl:16-31: the pullback of flash_attention returns (dq, dk, dv, dpair)."""

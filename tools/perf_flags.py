@@ -36,7 +36,7 @@ for (E, L, H, B) in ((64, 2048, 4, 4), (128, 2048, 8, 2)):
                     o, ms, ls = pkg._flash_attention(q, k, v, pr, causal=causal, kpad_mask=mk_)
                     tf = timeit(lambda: pkg._flash_attention(q, k, v, pr, causal=causal, kpad_mask=mk_))
                     tb = timeit(lambda: pkg.grad_flash_attention(do, o, ms, ls, q, k, v, pr, causal=causal, kpad_mask=mk_))
-                    fl = pkg.workmodel.attention_flops(E, L, L, H, B, causal=causal, kv_lens=lens.tolist() if use_mask else None)
+                    fl = pkg.workmodel.attention_flops(E, L, L, H, B, causal=causal, kv_lens=lens.tolist() if (use_mask and not causal) else None)
                     rec = dict(dtype=dtn, E=E, L=L, H=H, B=B, pair=use_pair, causal=causal, kpad=use_mask,
                                fwd_us=round(tf * 1e6, 1), bwd_us=round(tb * 1e6, 1), fwd_tflops=round(fl / tf / 1e12, 1),
                                bwd_tflops=round(2.5 * fl / tb / 1e12, 1))
