@@ -18,6 +18,9 @@ template <typename T, int E> struct BwdCfg {
     // 16-bit E = 128, large grids: 7 waves (224 keys / queries per workgroup) with single-buffered tiles ->
     // ~2 waves per SIMD instead of 1 (LDS-limited); small grids keep 4 waves (finer quantization over 256 CUs)
     static constexpr bool kBig7 = !kF32 && E > 64;
+    // 16-bit E <= 64 (K, V / Q, dO fragments live in registers): 8 waves per workgroup share each staged tile -- half the
+    // staging work and LDS traffic per wave at the same 2 waves per SIMD; used when the grid still fills the chip
+    static constexpr bool kWide8 = !kF32 && E <= 64;
     static constexpr int BK    = (E > 64) ? 32 : 64;
 };
 
@@ -103,6 +106,11 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
             const long long n7 = (long long)((d.kl + 223) / 224) * d.kh * d.batch;
             if (n7 >= big_thr) { st = launch_dkdv<T, E, 7, C::BQ, MODE>(d, p, s); done = true; }
         }
+        if constexpr (C::kWide8) {
+            const long long n8 = (long long)((d.kl + 255) / 256) * d.kh * d.batch;
+            const int nw = tune_get(kTuneBwdNW);
+            if (MODE != 2 && (nw == 8 || nw == 81 || (nw < 0 && !d.causal && n8 >= 256))) { st = launch_dkdv<T, E, 8, C::BQ, MODE>(d, p, s); done = true; }
+        }
         if (!done) st = launch_dkdv<T, E, C::NW_KV, C::BQ, MODE>(d, p, s);
         if (st != NNOP_OK) return st;
     }
@@ -113,6 +121,11 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         if constexpr (C::kBig7) {
             const long long n7 = (long long)((d.ql + 223) / 224) * d.qh * d.batch;
             if (n7 >= big_thr) { st = launch_dq<T, E, 7, C::BK, MODE>(d, p, s); done = true; }
+        }
+        if constexpr (C::kWide8) {
+            const long long n8 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
+            const int nw = tune_get(kTuneBwdNW);
+            if (MODE != 2 && (nw == 8 || nw == 82 || (nw < 0 && !d.causal && n8 >= 256))) { st = launch_dq<T, E, 8, C::BK, MODE>(d, p, s); done = true; }
         }
         if (!done) st = launch_dq<T, E, C::NW_Q, C::BK, MODE>(d, p, s);
         if (st != NNOP_OK) return st;

@@ -18,6 +18,7 @@ enum TuneKey {
     kTuneFwdW64,         // NNOP_FWD_W64     64-row-per-wave forward (fa_fwd_w64.hpp): 0 = never, 1 = wherever instantiated
     kTuneBwdBig7,        // NNOP_BWD_BIG7    workgroups from which the 7-wave E=128 backward form is used
     kTuneNormBwdCap,     // NNOP_NORM_BWD_CAP partial rows of the norm pullbacks
+    kTuneBwdNW,          // NNOP_BWD_NW      16-bit E <= 64 backward: waves per workgroup (4 | 8)
     kTuneFwdExactScale,  // NNOP_FWD_EXACT_SCALE  1 = 64-row forward applies scale*log2e in fp32 per logit instead of folding it into Q
     kTuneCount
 };

@@ -99,6 +99,32 @@ def test_pair_backward_staged_and_direct_paths(pkg, dev, dt, causal, pad, E, QH,
     assert torch.equal(outs[0][3], outs[1][3]), "dpair differs between the direct and the staged path"
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("E", [16, 32, 64])
+@pytest.mark.parametrize("case", ["plain", "causal", "pad", "gqa", "pair"])
+def test_eight_wave_backward_form(pkg, dev, tune, dt, E, case):
+    """16-bit E <= 64: the launcher uses 8-wave workgroups (256 keys / queries sharing each staged tile) for non-causal problems
+    that still fill the chip (csrc/fa_bwd_inst.hpp, kWide8).  Forced here on small shapes in every mode, ragged lengths included,
+    against the oracle and bitwise against the 4-wave form (same products per (query, key) pair in the same order)."""
+    QH, KH = (6, 2) if case == "gqa" else (2, 2)
+    d = make_inputs(18, 2, QH, KH, 517, 390, E, dt, dev, pair=(case == "pair"), pad=("lens" if case == "pad" else None))
+    causal = case == "causal"
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], d["pair"], causal=causal, kpad_mask=d["mask"])
+    outs = []
+    for nw in (4, 8):
+        tune(bwd_nw=nw)
+        outs.append(pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], d["pair"], causal=causal, kpad_mask=d["mask"]))
+    torch.cuda.synchronize()
+    rq, rk, rv, rp = oracle_bwd(d, causal)
+    for dq, dk, dv, dp in outs:
+        assert_close("dq", dq, rq, dt, kind="grad")
+        assert_close("dk", dk, rk, dt, kind="grad")
+        assert_close("dv", dv, rv, dt, kind="grad")
+        if dp is not None:
+            assert_close("dpair", dp, rp, dt, kind="grad")
+    assert torch.equal(outs[0][0], outs[1][0]), "dq differs between the 4-wave and the 8-wave form"
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_rrule_through_autograd(pkg, dev, dt):
     """src/attention_crc.jl:16-31: the pullback of flash_attention returns (dq, dk, dv, dpair)."""
