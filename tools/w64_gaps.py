@@ -53,7 +53,8 @@ def main():
         while i <= e:
             l = lines[i]
             m = re.match(r"s_cbranch\w* (\S+)", l)
-            if m and m.group(1) in labels and i < labels[m.group(1)] <= e and any("v_accvgpr_read" in x for x in lines[i:labels[m.group(1)]]):
+            rare = lambda blk: any("v_accvgpr_read" in x for x in blk) or sum("v_cndmask" in x for x in blk) >= 24     # rescale / mask blocks
+            if m and m.group(1) in labels and i < labels[m.group(1)] <= e and rare(lines[i:labels[m.group(1)]]):
                 i = labels[m.group(1)]
                 continue
             if not l.endswith(":"): path.append(l)

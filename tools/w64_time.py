@@ -23,10 +23,12 @@ for c in args:
     if mode == "lens":
         lens = torch.randint(KL // 4, KL + 1, (B,), generator=torch.Generator().manual_seed(2))
         mask = (torch.arange(KL)[None, :] < lens[:, None]).to(dev).contiguous()
+    if mode == "allvalid":                                  # masked-mode kernel on a problem without any masked element
+        mask = torch.ones(B, KL, dtype=torch.bool, device=dev)
     causal = mode == "causal"
     o = torch.empty_like(q); ms = torch.empty(B, QH, L, dtype=DT[dt], device=dev); ls = torch.empty_like(ms)
     f = lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal, kpad_mask=mask)
-    fl = pkg.workmodel.attention_flops(E, L, KL, QH, B, causal=causal, kv_lens=None if mask is None else lens.tolist())
+    fl = pkg.workmodel.attention_flops(E, L, KL, QH, B, causal=causal, kv_lens=None if lens is None else lens.tolist())
     est = fl / 0.8e9 + 5                                   # us per launch at ~800 TF
     nwarm, n = max(20, int(1.0e6 / est)), max(20, int(0.4e6 / est))
     for _ in range(nwarm): f()
