@@ -11,15 +11,15 @@
 //     AGPRs: ~440 v_accvgpr moves per kv tile, measured 1.3x slower -- DESIGN.md section 5), so every MFMA here is
 //     inline asm with explicit register classes ("a" = accumulator file): the compiler only allocates.
 //   * every K / V fragment read from LDS feeds TWO MFMAs (z = 0, 1): half the LDS bytes per FLOP of the 32-row forms.
-//   * K / V tiles arrive by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no staging registers, no
-//     ds_write): the LDS images are the same swizzled RowImg / blocked ColImg as everywhere else, the swizzle is applied
-//     to each lane's SOURCE address (the DMA destination is lane-linear); rings of 3 slots, loads issued two tiles
-//     ahead right after the tile's barrier, retired by a counted wait before the next barrier (raw s_barrier: the
-//     DMA stays in flight across everything else).
+//   * K / V tiles arrive by LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave-instruction, no staging registers, no
+//     ds_write; see "LDS-DMA" below): the LDS images are the same swizzled RowImg / blocked ColImg as everywhere else, the
+//     swizzle is applied to each lane's SOURCE offset (the DMA destination is lane-linear); rings of 3 slots, loads issued
+//     two tiles ahead right after the tile's barrier, retired by a wait before the next barrier (raw s_barrier: the DMA
+//     stays in flight across everything else).
 //   * one barrier per kv tile.  The loop body is software-pipelined across tiles and HAND-PLACED: it is a sequence of
-//     "slots" -- one MFMA, the LDS fragment read three fragments ahead, and a fixed share of the other tile's softmax
-//     VALU work (phase X: QK^T of tile t+1 beside exp / sum / convert of tile t; phase Y: PV of tile t beside the rest
-//     of the softmax and the row max of tile t+1) -- each closed by sched_barrier(0), because hipcc does not interleave
+//     "slots" -- the LDS fragment read three fragments ahead, one MFMA, and a share of the other tile's softmax VALU work
+//     dealt out by issue COST (W64Plan below: QK^T of tile t+1 beside exp / sum / convert of tile t; PV of tile t beside the
+//     rest of the softmax and the row max of tile t+1) -- each pinned by sched_barrier(0), because hipcc does not interleave
 //     inline-asm MFMAs with VALU work on its own (it models an asm statement as a 1-cycle instruction).
 //   * wait states the compiler would pad around a builtin MFMA are explicit (hipcc pads nothing around asm):
 //     MFMA result -> VALU read (fence_mfma_result), VALU result -> MFMA operand (fence_valu_operand).
