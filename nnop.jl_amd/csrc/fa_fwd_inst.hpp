@@ -132,15 +132,18 @@ static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
     if (b16 && (E == 64 || E == 128)) {
         // 64-row waves (fa_fwd_w64.hpp): 4 waves x 64 rows, one wave per SIMD with the whole register file.  Measured
-        // against the 32-row forms (bf16 / fp16, MI355X, profiles/r02/NOTES.md): E = 128 plain +32 %, causal +15 %,
-        // variable-length GQA +20 %; E = 64 plain +11 % at the headline shape and +17..26 % on larger grids, causal L >= 4096
-        // +4..17 %.  It needs >= one 256-row workgroup per CU, enough kv tiles to amortise its longer prologue (short or
-        // causal-and-short sequences stay on the 32-row kernels: -3..-20 % there), and (masked mode) the per-tile validity
-        // words in LDS.  Knob kTuneFwdW64: 0 never, 1 wherever instantiated, auto = the rule below.
+        // against the 32-row forms after the round-2 schedule work (bf16 / fp16, MI355X, tools/w64_check.py): faster wherever
+        // there are a few kv tiles and enough 256-row workgroups -- E = 64 plain +13..21 % from KL = 256 and 64 workgroups
+        // up; E = 64 causal / padded +10..20 % from KL = 512 and 128 workgroups; E = 128 +9..47 % from KL = 256, except plain
+        // problems with <= 128 workgroups (-3 %: the 32-row form splits them into twice as many) and KL = 128 (-33 %: the
+        // prologue).  Masked mode needs the per-tile validity words in LDS (KL <= 64 Ki), the pair-bias mode stays on the
+        // 32-row kernel.  Knob kTuneFwdW64: 0 never, 1 wherever instantiated, auto = the rule below.
         const int w64 = tune_get(kTuneFwdW64);
         // (its LDS-DMA addresses a (batch, kv-head) tensor through a 32-bit buffer offset)
         const bool fits = mode != 2 && (mode == 0 || d.kl <= 64 * kMaxMaskTiles) && (long long)d.kl * E * 2 < (1LL << 32);
-        const bool pays = wg256 >= 256 && (E == 128 ? d.kl >= 512 : (d.causal ? d.kl >= 4096 : d.kl >= 1024));
+        const bool masked = mode == 1;
+        const bool pays = E == 128 ? (d.kl >= 256 && (wg256 >= 160 || (masked && wg256 >= 64)))
+                                   : (masked ? (d.kl >= 512 && wg256 >= 128) : (d.kl >= 256 && wg256 >= 64));
         if (fits && (w64 == 1 || (w64 < 0 && pays))) return kFormW64;
     }
     if (b16 && E <= 64) {
