@@ -58,7 +58,7 @@ typedef enum nnop_status {
     NNOP_ERR_HEADS          = -4,  /* "Number of query heads must be divisible by ..."    (attention.jl:144) */
     NNOP_ERR_DTYPE          = -5,  /* dtype not one of nnop_dtype (Julia: MethodError)                       */
     NNOP_ERR_NULL           = -6,  /* a required pointer is NULL                                             */
-    NNOP_ERR_EMB_UNSUPPORTED= -7,  /* power of two but outside the kernels' range ("Failed to find groupsize
+    NNOP_ERR_EMB_UNSUPPORTED= -7,  /* power of two above 512 ("Failed to find groupsize
                                       ... Shared Memory constraint", attention.jl:204)                       */
     NNOP_ERR_SHAPE          = -8,  /* a non-positive / overflowing dimension                                 */
     NNOP_ERR_WORKSPACE      = -9,  /* workspace smaller than nnop_fa_bwd_workspace_bytes                      */

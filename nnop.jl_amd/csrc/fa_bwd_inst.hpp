@@ -5,6 +5,7 @@
 #pragma once
 #include "fa_bwd.hpp"
 #include "fa_launch.hpp"
+#include "fa_generic.hpp"
 #include <math.h>
 
 namespace nnop {
@@ -151,7 +152,33 @@ static int launch_bwd_e(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) 
     return launch_bwd_cfg<T, E, 0>(d, a, s);
 }
 
+template <typename T> static int launch_bwd_generic(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
+    BwdParams p;
+    p.dq = a.dq; p.dk = a.dk; p.dv = a.dv; p.dpair = a.pair ? a.dpair : nullptr;
+    p.d_o = a.d_o; p.o = a.o; p.ms = a.ms; p.ls = a.ls;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.pair = a.pair; p.kpad = a.kpad;
+    const long long n_rows = (long long)d.batch * d.qh * d.ql, n_krows = (long long)d.batch * d.kh * d.kl;
+    p.nl = (float*)a.workspace;
+    p.delta = p.nl + n_rows;
+    p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
+    p.causal = d.causal ? 1 : 0;
+    p.scale = (float)(1.0 / sqrt((double)d.emb));
+    p.n_blk = 0; p.n_wg = 0;
+    p.pair_a = p.pair_b = nullptr; p.dpair_s = nullptr; p.QLp = p.KLp = 0;
+    const long long gq = (n_rows + 3) / 4, gk = (n_krows + 3) / 4;
+    if (gq > 0x7fffffffLL || gk > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    if (p.dpair) {      // the dQ kernel writes dS only where a query sees the key
+        const size_t bytes = (size_t)d.batch * d.kl * d.ql * d.qh * sizeof(T);
+        if (hipMemsetAsync(p.dpair, 0, bytes, s) != hipSuccess) { (void)hipGetLastError(); return NNOP_ERR_HIP; }
+    }
+    hipLaunchKernelGGL((fa_bwd_generic_pre_kernel<T>), dim3((unsigned)gq), dim3(256), 0, s, p, d.emb, n_rows);
+    hipLaunchKernelGGL((fa_bwd_generic_dq_kernel<T>), dim3((unsigned)gq), dim3(256), 0, s, p, d.emb, n_rows);
+    hipLaunchKernelGGL((fa_bwd_generic_dkdv_kernel<T>), dim3((unsigned)gk), dim3(256), 0, s, p, d.emb, n_krows);
+    return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
+}
+
 template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
+    if (emb_generic(d.emb)) return launch_bwd_generic<T>(d, a, s);
     switch (d.emb) {
         case 16:  return launch_bwd_e<T, 16>(d, a, s);
         case 32:  return launch_bwd_e<T, 32>(d, a, s);

@@ -9,6 +9,7 @@
 #include "fa_fwd.hpp"
 #include "fa_fwd_split.hpp"
 #include "fa_fwd_w64.hpp"
+#include "fa_generic.hpp"
 #ifdef NNOP_DEV_BUILD
 #include "fa_fwd_split16.hpp"      // measured 7 % slower than the 32x32x16 body: experiments only (make DEV=1)
 #include <stdlib.h>
@@ -208,7 +209,23 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     return launch_fwd_mode<T, E, 4, 1>(d, a, s, mode);
 }
 
+template <typename T> static int launch_fwd_generic(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+    FwdParams p;
+    p.o = a.o; p.ms = a.ms; p.ls = a.ls;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.pair = a.pair; p.kpad = a.kpad;
+    p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
+    p.causal = d.causal ? 1 : 0;
+    p.n_qblk = 0; p.n_wg = 0;
+    p.scale = (float)(1.0 / sqrt((double)d.emb));
+    const long long n_rows = (long long)d.batch * d.qh * d.ql;
+    const long long grid = (n_rows + 3) / 4;
+    if (grid > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    hipLaunchKernelGGL((fa_fwd_generic_kernel<T>), dim3((unsigned)grid), dim3(256), 0, s, p, d.emb, n_rows);
+    return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
+}
+
 template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+    if (emb_generic(d.emb)) return launch_fwd_generic<T>(d, a, s);
     switch (d.emb) {
         case 16:  return launch_fwd_e<T, 16>(d, a, s);
         case 32:  return launch_fwd_e<T, 32>(d, a, s);

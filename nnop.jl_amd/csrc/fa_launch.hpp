@@ -49,7 +49,9 @@ int launch_layer_norm_bwd(const nnop_norm_desc& d, void* dx, void* dw, void* db,
 size_t norm_ws_bytes(const nnop_norm_desc& d, bool ln);
 
 // Embedding dims the MFMA kernels are instantiated for.
-inline bool emb_supported(int e) { return e == 16 || e == 32 || e == 64 || e == 128; }
+// MFMA-tiled kernels: 16, 32, 64, 128; every other power of two up to 512: fa_generic.hpp (correctness path)
+inline bool emb_tiled(int e) { return e == 16 || e == 32 || e == 64 || e == 128; }
+inline bool emb_supported(int e) { return e >= 1 && e <= 512 && (e & (e - 1)) == 0; }
 
 // bytes of backward scratch: two fp32 per query row (folded log-sum-exp, delta), [2][B][QH][QL]
 inline size_t bwd_workspace_bytes(const nnop_fa_desc& d) {

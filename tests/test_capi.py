@@ -83,8 +83,7 @@ def _desc(pkg, **kw):
     (dict(emb=48, emb_k=48), "NNOP_ERR_EMB_NOT_POW2"),
     (dict(qh=6, kh=4), "NNOP_ERR_HEADS"),
     (dict(dtype=7), "NNOP_ERR_DTYPE"),
-    (dict(emb=512), "NNOP_ERR_EMB_UNSUPPORTED"),
-    (dict(emb=8), "NNOP_ERR_EMB_UNSUPPORTED"),
+    (dict(emb=1024), "NNOP_ERR_EMB_UNSUPPORTED"),       # powers of two up to 512 run (csrc/fa_generic.hpp outside 16..128)
     (dict(ql=0), "NNOP_ERR_SHAPE"),
     (dict(), "NNOP_ERR_NULL"),                # valid descriptor, NULL tensors
 ])
