@@ -132,7 +132,7 @@ template <typename T, int E> struct BwdImgs {
 // registers during the compute phase and written after a barrier -- which frees the LDS for 7-wave workgroups
 // (224 keys: 112 KiB of K, V images + 32 KiB of tile), i.e. ~2 waves per SIMD instead of 1.
 // (chosen by the launcher: NW == 7 <=> single-buffered)
-template <typename T, int E, int NW> constexpr bool fa_bwd_single() { return sizeof(T) == 2 && E > 64 && NW == 7; }
+template <typename T, int E, int NW> constexpr bool fa_bwd_single() { return sizeof(T) == 2 && ((E > 64 && NW == 7) || E > 128); }
 
 template <typename T, int E, int NW, int BQ>
 constexpr int fa_bwd_dkdv_lds_bytes() {

@@ -13,12 +13,13 @@ namespace nnop {
 template <typename T, int E> struct BwdCfg {
     static constexpr bool kF32 = sizeof(T) == 4;
     // fp32 at E=128 keeps K,V (dkdv) / Q,dO (dq) in LDS instead of registers: fewer waves, smaller tiles
-    static constexpr int NW_KV = (kF32 && E > 64) ? 2 : 4;
+    // (16-bit E = 256: 2 waves, single-buffered tiles -- what fits 160 KiB of LDS)
+    static constexpr int NW_KV = ((kF32 && E > 64) || E > 128) ? 2 : 4;
     static constexpr int BQ    = (kF32 || E > 64) ? 32 : 64;
-    static constexpr int NW_Q  = (kF32 && E > 64) ? 2 : 4;
+    static constexpr int NW_Q  = ((kF32 && E > 64) || E > 128) ? 2 : 4;
     // 16-bit E = 128, large grids: 7 waves (224 keys / queries per workgroup) with single-buffered tiles ->
     // ~2 waves per SIMD instead of 1 (LDS-limited); small grids keep 4 waves (finer quantization over 256 CUs)
-    static constexpr bool kBig7 = !kF32 && E > 64;
+    static constexpr bool kBig7 = !kF32 && E == 128;
     // 16-bit E <= 64 (K, V / Q, dO fragments live in registers): 8 waves per workgroup share each staged tile -- half the
     // staging work and LDS traffic per wave at the same 2 waves per SIMD; used when the grid still fills the chip
     static constexpr bool kWide8 = !kF32 && E <= 64;
@@ -178,6 +179,9 @@ template <typename T> static int launch_bwd_generic(const nnop_fa_desc& d, const
 }
 
 template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        if (d.emb == 256) return launch_bwd_e<T, 256>(d, a, s);     // tiled kernels, 2 waves, single-buffered (see launch_fwd)
+    }
     if (emb_generic(d.emb)) return launch_bwd_generic<T>(d, a, s);
     switch (d.emb) {
         case 16:  return launch_bwd_e<T, 16>(d, a, s);

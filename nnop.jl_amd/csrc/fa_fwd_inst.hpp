@@ -30,7 +30,7 @@ template <typename T, int E, int NW, int MODE, int QB>
 static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
     // 64-key tiles, except the E = 128 pair-bias body (register budget) and fp32 E = 128
     // (LDS: 2 x (K + V) x 64 keys x 512 B = 128 KiB would leave one workgroup per CU)
-    constexpr int BK = (E >= 128 && (MODE == 2 || sizeof(T) == 4)) ? 32 : 64;
+    constexpr int BK = (E >= 256 || (E >= 128 && (MODE == 2 || sizeof(T) == 4))) ? 32 : 64;
     constexpr int lds = fa_fwd_lds_bytes<T, E, BK>();
     static_assert(lds <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
     auto kern = fa_fwd_kernel<T, E, NW, BK, MODE, QB>;
@@ -196,6 +196,7 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
         if (d.causal && wg128 >= 512 && (E <= 64 || d.ql <= 2048)) nw = 4;
     }
     if (E >= 128 && mode == 2) nw = 4;               // the E=128 pair-bias body: 4 waves per workgroup
+    if (E >= 256) nw = 4;                            // E = 256: one form (it spills at the 256-register cap as it is)
     if (const int t = tune_get(kTuneFwdNW); t == 4 || t == 8) nw = t;
 #ifdef NNOP_DEV_BUILD
     // QB = 2 with builtin MFMAs (experiment, make DEV=1): hipcc shuttles the score tiles between AGPRs and VGPRs
@@ -205,7 +206,9 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
         if (qb == 2 && mode == 0) return launch_fwd_cfg<T, E, 4, 0, 2>(d, a, s);
     }
 #endif
-    if (nw == 8) return launch_fwd_mode<T, E, 8, 1>(d, a, s, mode);
+    if constexpr (E < 256) {
+        if (nw == 8) return launch_fwd_mode<T, E, 8, 1>(d, a, s, mode);
+    }
     return launch_fwd_mode<T, E, 4, 1>(d, a, s, mode);
 }
 
@@ -225,6 +228,11 @@ template <typename T> static int launch_fwd_generic(const nnop_fa_desc& d, const
 }
 
 template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        // E = 256, 16-bit: the 32-row tiled kernel (32-key tiles; it spills some registers at the 256-register cap and is still
+        // ~50x the plain-HIP path).  fp32 E = 256 does not fit LDS and stays on fa_generic.hpp.
+        if (d.emb == 256) return launch_fwd_e<T, 256>(d, a, s);
+    }
     if (emb_generic(d.emb)) return launch_fwd_generic<T>(d, a, s);
     switch (d.emb) {
         case 16:  return launch_fwd_e<T, 16>(d, a, s);

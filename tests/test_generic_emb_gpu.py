@@ -42,3 +42,27 @@ def test_through_the_public_entry_point(pkg, dev):
     assert_close("dq", q.grad, rq, "bf16", kind="grad")
     assert_close("dk", k.grad, rk, "bf16", kind="grad")
     assert_close("dv", v.grad, rv, "bf16", kind="grad")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_e256_tiled_kernels_larger_shape_and_reproducibility(pkg, dev, dt, causal):
+    """16-bit E = 256 runs on the tiled MFMA kernels (32-key tiles, 2-wave single-buffered backward; they spill at the
+    256-register cap): a multi-tile, multi-workgroup shape with GQA and a ragged key length, and bitwise-equal repeat launches."""
+    d = make_inputs(21, 2, 4, 2, 389, 517, 256, dt, dev, pad="lens")
+    outs = []
+    for _ in range(2):
+        o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=causal, kpad_mask=d["mask"])
+        g = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=causal, kpad_mask=d["mask"])
+        torch.cuda.synchronize()
+        outs.append((o, ms, ls, *g[:3]))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+    o_ref, ms_ref, _ = oracle_fwd(d, causal)
+    rq, rk, rv, _ = oracle_bwd(d, causal)
+    o, ms, ls, dq, dk, dv = outs[0]
+    assert_close("o", o, o_ref, dt)
+    assert_close("ms", ms, ms_ref, dt)
+    assert_close("dq", dq, rq, dt, kind="grad")
+    assert_close("dk", dk, rk, dt, kind="grad")
+    assert_close("dv", dv, rv, dt, kind="grad")
