@@ -113,7 +113,7 @@ size_t nnop_fa_bwd_workspace_bytes(const nnop_fa_desc* d);
 /*
  * The same for a call WITH a pair bias (ABI version 5).  `pair` / `dpair` are [B][KL][QL][QH] with the head fastest
  * (src/attention.jl:62): per head their elements are QH apart, which a (batch, head) kernel can only touch one element per
- * lane.  Given this much scratch -- the small workspace + three head-major copies of the bias-sized tensor, padded to
+ * lane.  Given this much scratch -- the small workspace + two head-major bias-sized matrices (a copy of the bias, dS), padded to
  * multiples of 64 -- nnop_fa_bwd re-packs the bias once, runs its kernels on 16-byte accesses and unpacks dpair at the end
  * (bf16 E=64 L=2048 H=4 B=4: see DESIGN.md).  A caller that passes only nnop_fa_bwd_workspace_bytes() gets the same results
  * from the direct (slow) path; nnop_fa_bwd picks by `workspace_bytes`.  Returns 0 for an invalid descriptor.

@@ -48,7 +48,7 @@ struct BwdParams {
     int   n_wg;
     float scale;
     // MODE 3 (pair_tile.hpp): head-major scratch copies of the pair bias and the dS scratch, zero-padded to QLp x KLp
-    const void *pair_a, *pair_b;
+    const void* pair_a;
     void* dpair_s;
     int   QLp, KLp;
 };
@@ -298,9 +298,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
 
             typename PairTile<T>::Regs pregs;                              // kStaged: the bias tile, fetched ahead of the MFMAs
             if constexpr (kStaged) {
-                // rows = queries q0 .. q0+31 (register axis), columns = this wave's 32 keys (lane axis): copy B
-                const int kcol = kw0 < p.KLp - 32 ? kw0 : p.KLp - 32;     // a wave past KL stays inside the scratch
-                pregs = PairTile<T>::fetch((const T*)p.pair_b + (((size_t)b * p.QH + qh) * p.QLp + q0) * p.KLp + kcol, (size_t)p.KLp, lane);
+                // rows = this wave's 32 keys (its LANE axis), columns = queries q0 .. q0+31 (its register axis)
+                const int krow = kw0 < p.KLp - 32 ? kw0 : p.KLp - 32;     // a wave past KL stays inside the scratch
+                pregs = PairTile<T>::fetch((const T*)p.pair_a + (((size_t)b * p.QH + qh) * p.KLp + krow) * p.QLp + q0, (size_t)p.QLp, lane);
             }
             f32x16 s, dp;
 #pragma unroll
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             int qmax = 0;
             float pv[16];                                                  // kStaged: this lane's 16 bias values
             if constexpr (kStaged) {
-                PairTile<T>::unpack(pregs, smem + fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>() + wave * PairTile<T>::kBytes, lane, pv);
+                PairTile<T>::unpack_rows(pregs, smem + fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>() + wave * PairTile<T>::kBytes, lane, pv);
             } else if constexpr (kPair) {
                 pbase = (const T*)p.pair + (((size_t)b * p.KL + key_c) * p.QL + q0) * p.QH + qh;
                 qmax = p.QL - 1 - q0;                                      // last in-range local query row

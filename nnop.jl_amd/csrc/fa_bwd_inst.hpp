@@ -72,17 +72,17 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     p.causal = d.causal ? 1 : 0;
     p.scale = (float)(1.0 / sqrt((double)E));
     p.n_blk = 0; p.n_wg = 0;
-    p.pair_a = p.pair_b = nullptr; p.dpair_s = nullptr;
+    p.pair_a = nullptr; p.dpair_s = nullptr;
     p.QLp = pair_pad(d.ql); p.KLp = pair_pad(d.kl);
     if constexpr (MODE == 3) {
-        // scratch behind the two row vectors: copy A, copy B, dS (bwd_workspace_bytes_pair)
+        // scratch behind the two row vectors: the head-major copy of the bias, dS (bwd_workspace_bytes_pair)
         const size_t base = (bwd_workspace_bytes(d) + 255) & ~(size_t)255;
         const size_t one = (pair_scratch_elems(d) * sizeof(T) + 255) & ~(size_t)255;
         char* w = (char*)a.workspace + base;
-        p.pair_a = w; p.pair_b = w + one; p.dpair_s = w + 2 * one;
+        p.pair_a = w; p.dpair_s = w + one;
         const long long nblk = (long long)d.batch * (p.KLp / 32) * (p.QLp / 32);
         if (nblk > 0x7fffffffLL) return NNOP_ERR_SHAPE;
-        PairPackParams pp{a.pair, (void*)p.pair_a, (void*)p.pair_b, d.ql, d.kl, d.qh, d.batch, p.QLp, p.KLp, d.causal ? 1 : 0};
+        PairPackParams pp{a.pair, (void*)p.pair_a, d.ql, d.kl, d.qh, d.batch, p.QLp, p.KLp, d.causal ? 1 : 0};
         hipLaunchKernelGGL((pair_pack_kernel<T>), dim3((unsigned)nblk), dim3(256), 1024 * d.qh * sizeof(T), s, pp);
     }
 
@@ -165,7 +165,7 @@ template <typename T> static int launch_bwd_generic(const nnop_fa_desc& d, const
     p.causal = d.causal ? 1 : 0;
     p.scale = (float)(1.0 / sqrt((double)d.emb));
     p.n_blk = 0; p.n_wg = 0;
-    p.pair_a = p.pair_b = nullptr; p.dpair_s = nullptr; p.QLp = p.KLp = 0;
+    p.pair_a = nullptr; p.dpair_s = nullptr; p.QLp = p.KLp = 0;
     const long long gq = (n_rows + 3) / 4, gk = (n_krows + 3) / 4;
     if (gq > 0x7fffffffLL || gk > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     if (p.dpair) {      // the dQ kernel writes dS only where a query sees the key

@@ -57,7 +57,7 @@ inline bool emb_supported(int e) { return e >= 1 && e <= 512 && (e & (e - 1)) ==
 inline size_t bwd_workspace_bytes(const nnop_fa_desc& d) {
     return 2 * (size_t)d.batch * d.qh * d.ql * sizeof(float);
 }
-// With a pair bias: the same + three head-major scratch matrices (two copies of the bias, one dS), each
+// With a pair bias: the same + two head-major scratch matrices (a copy of the bias, dS), each
 // [B][QH][pad64(KL)][pad64(QL)] elements, 256-byte aligned (pair_tile.hpp).  0 when the staged path does not apply
 // (the pack kernel's LDS block holds 32 x 32 x QH elements).
 inline size_t pair_scratch_elems(const nnop_fa_desc& d) {
@@ -72,7 +72,7 @@ inline size_t bwd_workspace_bytes_pair(const nnop_fa_desc& d) {
     if (!pair_staged_ok(d)) return bwd_workspace_bytes(d);
     const size_t es = d.dtype == NNOP_F32 ? 4 : 2;
     const size_t one = (pair_scratch_elems(d) * es + 255) & ~(size_t)255;
-    return base + 3 * one;
+    return base + 2 * one;
 }
 
 

@@ -6,13 +6,13 @@
 // count, not the bytes, was the whole cost of the pair-bias backward (round 1: dQ kernel 405 us with bias, 40 without).
 //
 // With scratch space from the caller's workspace (nnop_fa_bwd_workspace_bytes_pair) the backward instead runs
-//   1. pair_pack_kernel    pair -> two head-major copies, zero-padded to multiples of 64:
-//                            A [B][QH][KLp][QLp] (q contiguous)   for the dQ kernel   (lane = query, registers = keys)
-//                            B [B][QH][QLp][KLp] (k contiguous)   for the dK/dV kernel (lane = key,   registers = queries)
-//   2. the two kernels in MODE 3: a wave moves its 32 x 32 bias tile with two 16-byte loads per lane into a wave-private
-//      LDS tile and picks it up in accumulator layout with the hardware-transposed LDS read (PairTile::load: 2 global
-//      loads + 2 LDS writes + 4 LDS reads instead of 16 global loads); the dQ kernel writes dS the same way into
-//      S [B][QH][QLp][KLp] (PairTile::store: 4 LDS writes + 2 LDS reads + 2 global 16-byte stores instead of 16 stores)
+//   1. pair_pack_kernel    pair -> one head-major copy A [B][QH][KLp][QLp] (q contiguous), zero-padded to multiples of 64
+//   2. the two kernels in MODE 3: a wave moves its 32 x 32 bias tile with two 16-byte loads per lane (PairTile::fetch, ahead
+//      of the MFMAs) into a wave-private LDS tile and picks it up in accumulator layout -- the dQ kernel (lane = query,
+//      registers = keys) with the hardware-transposed LDS read (unpack), the dK/dV kernel (lane = key, registers =
+//      queries) from its own row of a padded row-major tile (unpack_rows): 2 global loads + 2-4 LDS writes + 4 LDS reads
+//      instead of 16 two-byte global loads; the dQ kernel writes dS the reverse way into
+//      S [B][QH][QLp][KLp] (PairTile::store: 4 LDS writes + 4 LDS reads + 2 global 16-byte stores instead of 16 stores)
 //   3. dpair_unpack_kernel  S -> dpair, writing zeros where no tile was visited (causally hidden or padded keys).
 // MODE 2 (direct 2-byte accesses, dpair zero-filled first) stays as the path for callers that pass the small workspace.
 #pragma once
@@ -23,7 +23,9 @@ namespace nnop {
 __host__ __device__ constexpr int pair_pad(int n) { return (n + 63) & ~63; }
 
 template <typename T> struct PairTile {
-    static constexpr int kBytes = 32 * 32 * (int)sizeof(T);      // wave-private LDS tile
+    // wave-private LDS tile: 32 x 32 elements; the row-major variant (unpack_rows) pads its rows against bank conflicts
+    static constexpr int kRowPad = sizeof(T) == 2 ? 72 : 132;    // bytes per padded row
+    static constexpr int kBytes = 32 * kRowPad;
     using Img = ColImg<T, 32>;
 
     // 32 x 32 tile at `g` (row stride `ld` elements, 16-byte aligned rows): rows = the kernel's accumulator REGISTER axis,
@@ -61,6 +63,41 @@ template <typename T> struct PairTile {
             for (int i = 0; i < 16; ++i) out[i] = *reinterpret_cast<const float*>(lds + acc_row(i, h) * 128 + 4 * r);
         }
         __builtin_amdgcn_wave_barrier();                         // the tile may be overwritten (store) right away
+    }
+
+    // Same registers, other orientation: out[i] = tile[r][acc_row(i, h)] -- the lane's own ROW of the tile (rows = the kernel's
+    // LANE axis, columns = its register axis).  The dK/dV kernel (lane = key) reads the q-contiguous copy of the bias this
+    // way, so that one head-major copy serves both kernels.  Row-major LDS tile with padded rows (72 / 132 bytes: a lane's
+    // 8-byte / 4-byte reads then spread over the banks).
+    NNOP_DEV static void unpack_rows(const Regs& x, char* lds, int lane, float (&out)[16]) {
+        const int r = lane & 31, h = lane >> 5;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                char* d = lds + (16 * j + (lane >> 2)) * kRowPad + 16 * (lane & 3);
+                *reinterpret_cast<u32x2*>(d) = u32x2{x.v[j][0], x.v[j][1]};
+                *reinterpret_cast<u32x2*>(d + 8) = u32x2{x.v[j][2], x.v[j][3]};
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typedef T t4 __attribute__((ext_vector_type(4)));
+                const t4 w = __builtin_bit_cast(t4, *reinterpret_cast<const u32x2*>(lds + r * kRowPad + (8 * g + 4 * h) * 2));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[4 * g + j] = to_f32(w[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* d = reinterpret_cast<float*>(lds + (8 * j + (lane >> 3)) * kRowPad + 16 * (lane & 7));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = __uint_as_float(x.v[j][e]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) out[i] = *reinterpret_cast<const float*>(lds + r * kRowPad + 4 * acc_row(i, h));
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 
     // The reverse for dS: v[i] belongs to (lane axis r, register axis acc_row(i, h)).
@@ -105,7 +142,7 @@ template <typename T> struct PairTile {
 
 struct PairPackParams {
     const void* pair;        // [B][KL][QL][QH]
-    void *a, *b;             // [B][QH][KLp][QLp], [B][QH][QLp][KLp]
+    void* a;                 // [B][QH][KLp][QLp]
     int QL, KL, QH, B, QLp, KLp, causal;
 };
 
@@ -164,16 +201,12 @@ __global__ __launch_bounds__(256) void pair_pack_kernel(const PairPackParams p) 
     }
     __syncthreads();
     T* pa = (T*)p.a;
-    T* pb = (T*)p.b;
-    // 16-byte chunks of the outputs: A rows = keys (chunk = N queries), B rows = queries (chunk = N keys); 32 / N chunks per row
+    // 16-byte chunks of the output: rows = keys, chunk = N queries (LDS stride QH); 32 / N chunks per row
     constexpr int CPR = 32 / N;
     for (int i = tid; i < p.QH * 32 * CPR; i += 256) {
         const int c = i % CPR, row = (i / CPR) & 31, hh = i / (CPR * 32);
-        // A[key = row][queries N c ..]: LDS stride QH;   B[query = row][keys N c ..]: LDS stride 32 QH
         *reinterpret_cast<u32x4*>(pa + (((size_t)b * p.QH + hh) * p.KLp + k0 + row) * p.QLp + q0 + N * c) =
             gather16<T>(tile + (row * 32 + N * c) * p.QH + hh, p.QH);
-        *reinterpret_cast<u32x4*>(pb + (((size_t)b * p.QH + hh) * p.QLp + q0 + row) * p.KLp + k0 + N * c) =
-            gather16<T>(tile + (N * c * 32 + row) * p.QH + hh, run);
     }
 }
 
