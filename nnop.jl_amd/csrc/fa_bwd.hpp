@@ -35,6 +35,13 @@
 #include "fa_common.hpp"
 #include "pair_tile.hpp"
 
+// 16-bit dQ kernel: up to which E the wave keeps its Q and dO fragments in registers (above: re-read from LDS every tile)
+// K, V fragments of the dK/dV kernel in registers up to this E (at 128 the dK^T / dV^T accumulators already take 128 registers:
+// measured 36-124 spilled registers with the fragments on top)
+#ifndef NNOP_DKDV_KVREGS_MAXE
+#define NNOP_DKDV_KVREGS_MAXE 64
+#endif
+
 namespace nnop {
 
 struct BwdParams {
@@ -136,7 +143,7 @@ template <typename T, int E, int NW> constexpr bool fa_bwd_single() { return siz
 
 template <typename T, int E, int NW, int BQ>
 constexpr int fa_bwd_dkdv_lds_bytes() {
-    constexpr bool kv_regs = E <= 64;
+    constexpr bool kv_regs = E <= NNOP_DKDV_KVREGS_MAXE;
     constexpr int nbuf = fa_bwd_single<T, E, NW>() ? 1 : 2;
     return (kv_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) + nbuf * (2 * BwdImgs<T, E>::both(BQ) + 2 * BQ * 4);
 }
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     constexpr int KS = E / 16;
     constexpr int EB = (E + 31) / 32;
     constexpr int QB = BQ / 32;
-    constexpr bool kKVRegs = E <= 64;     // E = 128: dK^T, dV^T accumulators already take 128 registers
+    constexpr bool kKVRegs = E <= NNOP_DKDV_KVREGS_MAXE;     // E = 128: dK^T, dV^T accumulators already take 128 registers
     constexpr int KVIMG = kKVRegs ? 0 : Row::bytes(32 * NW);
     constexpr int QIMG = Imgs::both(BQ);
     constexpr bool kSingle = fa_bwd_single<T, E, NW>();
@@ -415,10 +422,16 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
 //   dQ^T += K^T dS^T : A = K columns (LDS transposed read), B = dS^T straight from accumulators
 // -------------------------------------------------------------------------------------------------
 constexpr int kMaxMaskTilesBwd = 1024;       // key padding: one 64-bit validity word per kv tile (see fa_fwd.hpp)
-template <typename T, int E, int NW, int BK>
+// dQ kernel: does a wave keep its Q and dO fragments in registers for the whole kernel (else they are re-read from LDS row
+// images every tile)?  16-bit: E <= 64 always; E = 128 in the plain / masked modes (252-256 registers, no spills; the
+// pair-bias modes would spill ~50) -- which also frees 112 KiB of LDS: those kernels are double-buffered and run 8 waves.
+template <typename T, int E, int MODE> constexpr bool fa_bwd_dq_qregs() {
+    return sizeof(T) == 2 ? (E <= 64 || (E == 128 && MODE <= 1)) : E <= 32;
+}
+template <typename T, int E, int NW, int BK, int MODE>
 constexpr int fa_bwd_dq_lds_bytes() {
-    constexpr bool qdo_regs = E <= (sizeof(T) == 2 ? 64 : 32);
-    constexpr int nbuf = fa_bwd_single<T, E, NW>() ? 1 : 2;
+    constexpr bool qdo_regs = fa_bwd_dq_qregs<T, E, MODE>();
+    constexpr int nbuf = (fa_bwd_single<T, E, NW>() && !qdo_regs) ? 1 : 2;
     return (qdo_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) +
            nbuf * (BwdImgs<T, E>::both(BK) + RowImg<T, E>::bytes(BK)) + 8 * kMaxMaskTilesBwd;   // + validity words
 }
@@ -436,10 +449,10 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     constexpr int KS = E / 16;
     constexpr int EB = (E + 31) / 32;
     constexpr int KB = BK / 32;
-    constexpr bool kQRegs = E <= (sizeof(T) == 2 ? 64 : 32);   // else Q, dO fragments come from LDS row images
+    constexpr bool kQRegs = fa_bwd_dq_qregs<T, E, MODE>();     // else Q, dO fragments come from LDS row images
     constexpr int QIMG = kQRegs ? 0 : Row::bytes(32 * NW);
     constexpr int KIMG = Imgs::both(BK);
-    constexpr bool kSingle = fa_bwd_single<T, E, NW>();
+    constexpr bool kSingle = fa_bwd_single<T, E, NW>() && !kQRegs;
     constexpr int BUF = kSingle ? 0 : KIMG + Row::bytes(BK);      // distance between the two buffers (0: one buffer)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -478,7 +491,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         if (mp) {
             // variable sequence length: validity words in LDS + stop after the tile holding the last valid key (as the
             // forward does); no valid key at all -> 0 tiles -> dQ = 0
-            uint64_t* vbits = reinterpret_cast<uint64_t*>(smem + (fa_bwd_dq_lds_bytes<T, E, NW, BK>() - 8 * kMaxMaskTilesBwd));
+            uint64_t* vbits = reinterpret_cast<uint64_t*>(smem + (fa_bwd_dq_lds_bytes<T, E, NW, BK, MODE>() - 8 * kMaxMaskTilesBwd));
             int* slot = reinterpret_cast<int*>(smem);
             const int nk = n_tiles * BK < p.KL ? n_tiles * BK : p.KL;
             const int last = kpad_scan(mp, p.KL, nk, vbits, kMaxMaskTilesBwd, slot, tid, NT);
@@ -557,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             if (mp) {
                 if ((t * BK) >> 6 < kMaxMaskTilesBwd) {
                     valid &= kpad_tile_bits<BK>(reinterpret_cast<const uint64_t*>(
-                        smem + (fa_bwd_dq_lds_bytes<T, E, NW, BK>() - 8 * kMaxMaskTilesBwd)), t);
+                        smem + (fa_bwd_dq_lds_bytes<T, E, NW, BK, MODE>() - 8 * kMaxMaskTilesBwd)), t);
                 } else {
                     const int kk = k0 + lane;
                     const bool lv = (lane < BK && kk < p.KL) ? (mp[kk] != 0) : false;
@@ -603,7 +616,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                 float pv[16];                                              // kStaged: this lane's 16 bias values
                 char* ptile = nullptr;
                 if constexpr (kStaged) {
-                    ptile = smem + fa_bwd_dq_lds_bytes<T, E, NW, BK>() + wave * PairTile<T>::kBytes;
+                    ptile = smem + fa_bwd_dq_lds_bytes<T, E, NW, BK, MODE>() + wave * PairTile<T>::kBytes;
                     PairTile<T>::unpack(pregs, ptile, lane, pv);
                 } else if constexpr (kPair) {
                     kstride = p.QL * p.QH;

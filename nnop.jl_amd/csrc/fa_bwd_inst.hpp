@@ -44,7 +44,7 @@ static int launch_dkdv(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s)
 
 template <typename T, int E, int NW, int BK, int MODE>
 static int launch_dq(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
-    constexpr int lds = fa_bwd_dq_lds_bytes<T, E, NW, BK>() + (MODE == 3 ? NW * PairTile<T>::kBytes : 0);
+    constexpr int lds = fa_bwd_dq_lds_bytes<T, E, NW, BK, MODE>() + (MODE == 3 ? NW * PairTile<T>::kBytes : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = fa_bwd_dq_kernel<T, E, NW, BK, MODE>;
     static unsigned long long lds_done = 0;
@@ -121,8 +121,10 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         int st = NNOP_OK;
         bool done = false;
         if constexpr (C::kBig7) {
-            const long long n7 = (long long)((d.ql + 223) / 224) * d.qh * d.batch;
-            if (n7 >= big_thr) { st = launch_dq<T, E, 7, C::BK, MODE>(d, p, s); done = true; }
+            // 8 waves where Q, dO live in registers (no LDS images of them: double-buffered tiles fit), else 7 single-buffered
+            constexpr int NWB = fa_bwd_dq_qregs<T, E, MODE>() ? 8 : 7;
+            const long long nb = (long long)((d.ql + 32 * NWB - 1) / (32 * NWB)) * d.qh * d.batch;
+            if (nb >= big_thr) { st = launch_dq<T, E, NWB, C::BK, MODE>(d, p, s); done = true; }
         }
         if constexpr (C::kWide8) {
             const long long n8 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
