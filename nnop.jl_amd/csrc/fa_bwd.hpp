@@ -36,10 +36,10 @@
 #include "pair_tile.hpp"
 
 // 16-bit dQ kernel: up to which E the wave keeps its Q and dO fragments in registers (above: re-read from LDS every tile)
-// K, V fragments of the dK/dV kernel in registers up to this E (at 128 the dK^T / dV^T accumulators already take 128 registers:
-// measured 36-124 spilled registers with the fragments on top)
-#ifndef NNOP_DKDV_KVREGS_MAXE
-#define NNOP_DKDV_KVREGS_MAXE 64
+// dK/dV kernel at E = 128 (16-bit, plain / masked modes): K fragments in registers, V fragments from LDS (both in registers on
+// top of the 128 registers of dK^T / dV^T accumulators: 36-124 spilled registers, measured).  0 = both from LDS (round 1).
+#ifndef NNOP_DKDV_KREGS128
+#define NNOP_DKDV_KREGS128 1
 #endif
 
 namespace nnop {
@@ -141,11 +141,21 @@ template <typename T, int E> struct BwdImgs {
 // (chosen by the launcher: NW == 7 <=> single-buffered)
 template <typename T, int E, int NW> constexpr bool fa_bwd_single() { return sizeof(T) == 2 && ((E > 64 && NW == 7) || E > 128); }
 
-template <typename T, int E, int NW, int BQ>
+// dK/dV kernel: which of the workgroup's K / V fragments live in registers for the whole kernel (else: LDS row images)
+template <typename T, int E, int MODE> constexpr bool fa_bwd_dkdv_vregs() { return E <= 64; }
+template <typename T, int E, int MODE, int NW = 8> constexpr bool fa_bwd_dkdv_kregs() {
+    // E = 128: only the 8-wave form (the 4-wave masked kernel spills 25 registers with K on top and measured 2 % slower)
+    return E <= 64 || (NNOP_DKDV_KREGS128 && sizeof(T) == 2 && E == 128 && MODE <= 1 && NW == 8);
+}
+// with K out of LDS the streamed tiles fit twice even at 7 / 8 waves
+template <typename T, int E, int NW, int MODE> constexpr bool fa_bwd_dkdv_single() {
+    return fa_bwd_single<T, E, NW>() && !(E == 128 && fa_bwd_dkdv_kregs<T, E, MODE, NW>());
+}
+template <typename T, int E, int NW, int BQ, int MODE>
 constexpr int fa_bwd_dkdv_lds_bytes() {
-    constexpr bool kv_regs = E <= NNOP_DKDV_KVREGS_MAXE;
-    constexpr int nbuf = fa_bwd_single<T, E, NW>() ? 1 : 2;
-    return (kv_regs ? 0 : 2 * RowImg<T, E>::bytes(32 * NW)) + nbuf * (2 * BwdImgs<T, E>::both(BQ) + 2 * BQ * 4);
+    constexpr int nbuf = fa_bwd_dkdv_single<T, E, NW, MODE>() ? 1 : 2;
+    return (fa_bwd_dkdv_kregs<T, E, MODE, NW>() ? 0 : RowImg<T, E>::bytes(32 * NW)) + (fa_bwd_dkdv_vregs<T, E, MODE>() ? 0 : RowImg<T, E>::bytes(32 * NW)) +
+           nbuf * (2 * BwdImgs<T, E>::both(BQ) + 2 * BQ * 4);
 }
 
 // MODE 0 plain / 1 masked (causal, key padding) / 2 masked + pair bias and dpair  (as in fa_fwd.hpp)
@@ -162,10 +172,10 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     constexpr int KS = E / 16;
     constexpr int EB = (E + 31) / 32;
     constexpr int QB = BQ / 32;
-    constexpr bool kKVRegs = E <= NNOP_DKDV_KVREGS_MAXE;     // E = 128: dK^T, dV^T accumulators already take 128 registers
-    constexpr int KVIMG = kKVRegs ? 0 : Row::bytes(32 * NW);
+    constexpr bool kKRegs = fa_bwd_dkdv_kregs<T, E, MODE, NW>(), kVRegs = fa_bwd_dkdv_vregs<T, E, MODE>();
+    constexpr int KIMG_B = kKRegs ? 0 : Row::bytes(32 * NW), VIMG_B = kVRegs ? 0 : Row::bytes(32 * NW);
     constexpr int QIMG = Imgs::both(BQ);
-    constexpr bool kSingle = fa_bwd_single<T, E, NW>();
+    constexpr bool kSingle = fa_bwd_dkdv_single<T, E, NW, MODE>();
     constexpr int BUF = kSingle ? 0 : 2 * QIMG + 2 * BQ * 4;      // distance between the two buffers (0: one buffer)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -208,21 +218,24 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     }
 
     // ---- K, V fragments (B operands: k = embedding, column = key on the lane) ------------------
-    frag_t kf[kKVRegs ? KS : 1], vf[kKVRegs ? KS : 1];
+    frag_t kf[kKRegs ? KS : 1], vf[kVRegs ? KS : 1];
     char* kimg = smem;
-    char* vimg = smem + KVIMG;
-    char* bufs = smem + 2 * KVIMG;
-    if constexpr (kKVRegs) {
+    char* vimg = smem + KIMG_B;
+    char* bufs = smem + KIMG_B + VIMG_B;
+    if constexpr (kKRegs) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = *reinterpret_cast<const frag_t*>(kp + (size_t)key_c * E + 16 * ks + 8 * h);
-            vf[ks] = *reinterpret_cast<const frag_t*>(vp + (size_t)key_c * E + 16 * ks + 8 * h);
-        }
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const frag_t*>(kp + (size_t)key_c * E + 16 * ks + 8 * h);
     } else {
-        Stager<T, E, 32 * NW, NT> sk, sv;
+        Stager<T, E, 32 * NW, NT> sk;
         sk.load(kp + (size_t)k0wg * E, p.KL - k0wg, tid);
-        sv.load(vp + (size_t)k0wg * E, p.KL - k0wg, tid);
         sk.template write<Row>(kimg, tid);
+    }
+    if constexpr (kVRegs) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) vf[ks] = *reinterpret_cast<const frag_t*>(vp + (size_t)key_c * E + 16 * ks + 8 * h);
+    } else {
+        Stager<T, E, 32 * NW, NT> sv;
+        sv.load(vp + (size_t)k0wg * E, p.KL - k0wg, tid);
         sv.template write<Row>(vimg, tid);
     }
 
@@ -277,9 +290,13 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         stage_load(0);
         stage_write(bufs);
     }
-    if constexpr (kKVRegs) {
+    if constexpr (kKRegs) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { landed(kf[ks]); landed(vf[ks]); }
+        for (int ks = 0; ks < KS; ++ks) landed(kf[ks]);
+    }
+    if constexpr (kVRegs) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) landed(vf[ks]);
     }
     __syncthreads();
 
@@ -320,11 +337,10 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 frag_t kfr, vfr;
-                if constexpr (kKVRegs) { kfr = kf[ks]; vfr = vf[ks]; }
-                else {
-                    kfr = Row::read_row_frag(kimg, 32 * wave + r, h, ks);
-                    vfr = Row::read_row_frag(vimg, 32 * wave + r, h, ks);
-                }
+                if constexpr (kKRegs) kfr = kf[ks];
+                else kfr = Row::read_row_frag(kimg, 32 * wave + r, h, ks);
+                if constexpr (kVRegs) vfr = vf[ks];
+                else vfr = Row::read_row_frag(vimg, 32 * wave + r, h, ks);
                 s  = mma16<T>(Row::read_row_frag(qrow, 32 * qb + r, h, ks), kfr, s);
                 dp = mma16<T>(Row::read_row_frag(dorow, 32 * qb + r, h, ks), vfr, dp);
             }
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             int qmax = 0;
             float pv[16];                                                  // kStaged: this lane's 16 bias values
             if constexpr (kStaged) {
-                PairTile<T>::unpack_rows(pregs, smem + fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>() + wave * PairTile<T>::kBytes, lane, pv);
+                PairTile<T>::unpack_rows(pregs, smem + fa_bwd_dkdv_lds_bytes<T, E, NW, BQ, MODE>() + wave * PairTile<T>::kBytes, lane, pv);
             } else if constexpr (kPair) {
                 pbase = (const T*)p.pair + (((size_t)b * p.KL + key_c) * p.QL + q0) * p.QH + qh;
                 qmax = p.QL - 1 - q0;                                      // last in-range local query row

@@ -28,7 +28,7 @@ template <typename T, int E> struct BwdCfg {
 
 template <typename T, int E, int NW, int BQ, int MODE>
 static int launch_dkdv(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
-    constexpr int lds = fa_bwd_dkdv_lds_bytes<T, E, NW, BQ>() + (MODE == 3 ? NW * PairTile<T>::kBytes : 0);
+    constexpr int lds = fa_bwd_dkdv_lds_bytes<T, E, NW, BQ, MODE>() + (MODE == 3 ? NW * PairTile<T>::kBytes : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = fa_bwd_dkdv_kernel<T, E, NW, BQ, MODE>;
     static unsigned long long lds_done = 0;
@@ -105,8 +105,10 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         int st = NNOP_OK;
         bool done = false;
         if constexpr (C::kBig7) {
-            const long long n7 = (long long)((d.kl + 223) / 224) * d.kh * d.batch;
-            if (n7 >= big_thr) { st = launch_dkdv<T, E, 7, C::BQ, MODE>(d, p, s); done = true; }
+            // 8 waves double-buffered where K lives in registers (64 KiB of V images + 2 x 32 KiB of tiles), else 7 single-buffered
+            constexpr int NWB = fa_bwd_dkdv_kregs<T, E, MODE>() ? 8 : 7;
+            const long long nb = (long long)((d.kl + 32 * NWB - 1) / (32 * NWB)) * d.kh * d.batch;
+            if (nb >= big_thr) { st = launch_dkdv<T, E, NWB, C::BQ, MODE>(d, p, s); done = true; }
         }
         if constexpr (C::kWide8) {
             const long long n8 = (long long)((d.kl + 255) / 256) * d.kh * d.batch;
