@@ -99,7 +99,9 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         if (hipMemsetAsync(p.dpair, 0, bytes, s) != hipSuccess) { (void)hipGetLastError(); return NNOP_ERR_HIP; }
     }
     const int big_tune = tune_get(kTuneBwdBig7);
-    const int big_thr = big_tune >= 0 ? big_tune : 512;    // workgroups (7-wave form) from which it is used
+    // workgroups of the 7 / 8-wave E = 128 forms from which they are used: one per CU when every block has the same work,
+    // two per CU under a causal mask (measured, tools/bwd_ab.py: 256 blocks non-causal +27 %, causal -9 %)
+    const int big_thr = big_tune >= 0 ? big_tune : (d.causal ? 512 : 256);
     // 3. dK, dV
     {
         int st = NNOP_OK;
