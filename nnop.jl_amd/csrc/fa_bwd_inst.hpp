@@ -151,7 +151,9 @@ template <typename T, int E>
 static int launch_bwd_e(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
     if (a.pair) {
         // staged pair path when the caller brought the scratch for it (nnop_fa_bwd_workspace_bytes_pair)
-        if (pair_staged_ok(d) && a.workspace_bytes >= bwd_workspace_bytes_pair(d) && bwd_workspace_bytes_pair(d) > bwd_workspace_bytes(d))
+        // (the scratch matrices are addressed with 16-byte vectors: a workspace that is not 16-byte aligned takes the direct path)
+        if (pair_staged_ok(d) && a.workspace_bytes >= bwd_workspace_bytes_pair(d) && bwd_workspace_bytes_pair(d) > bwd_workspace_bytes(d) &&
+            ((uintptr_t)a.workspace & 15) == 0)
             return launch_bwd_cfg<T, E, 3>(d, a, s);
         return launch_bwd_cfg<T, E, 2>(d, a, s);
     }
