@@ -58,6 +58,9 @@
 #ifndef NNOP_W64_MFMASUM
 #define NNOP_W64_MFMASUM 1
 #endif
+#ifndef NNOP_W64_SUM_MAXE
+#define NNOP_W64_SUM_MAXE 64
+#endif
 #ifndef NNOP_W64_RF8
 #define NNOP_W64_RF8 0
 #endif
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     constexpr float kThr = 8.0f;
     constexpr uint64_t kFull = ~0ull;
     constexpr bool kPre = PRE && NNOP_W64_PRESCALE != 0;     // logits leave the MFMA as (s * scale * log2e - reference)
-    constexpr bool kSum = NNOP_W64_MFMASUM != 0 && E <= 64;  // row sums on the matrix pipe (E = 128: measured 1.7 % slower)
+    constexpr bool kSum = NNOP_W64_MFMASUM != 0 && E <= NNOP_W64_SUM_MAXE;  // row sums on the matrix pipe (E = 128: 1.7 % slower before the planner, 3.5 % slower with it: 2863 vs 2770 cycles per tile)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #if NNOP_W64_STAMP
