@@ -20,3 +20,17 @@ def test_shipped_w64_kernels_pass_the_audit():
 def test_audit_flags_the_build_without_leave_fences():
     r = subprocess.run([sys.executable, AUDIT, "--flags", "-DNNOP_W64_NO_LEAVE_FENCE=1"], capture_output=True, text=True)
     assert r.returncode == 1 and "before the MFMA writing it is done" in r.stdout, r.stdout + r.stderr
+
+
+def test_schedule_of_the_generated_loop_stays_balanced():
+    """The slots of the hand-placed loop are dealt out by issue cost (W64Plan).  tools/w64_gaps.py prices the MFMA-to-MFMA gaps
+    of the GENERATED code with the calibrated costs (profiles/r02/gapcost.log); a change that lets hipcc pile work into a few
+    gaps, or adds instructions to the loop, shows up as predicted cycles per MFMA (round 2: 43.1 at E = 64, 40.0 at E = 128;
+    the measured 46.2 / 42.5 track them)."""
+    import re
+    gaps = os.path.join(ROOT, "tools", "w64_gaps.py")
+    r = subprocess.run([sys.executable, gaps, "Li0ELb1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    per = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"Li(\d+)ELi0ELb1\w*: .*? ([\d.]+) per MFMA", r.stdout)}
+    assert set(per) == {64, 128}, r.stdout
+    assert per[64] <= 45.0 and per[128] <= 41.5, per
