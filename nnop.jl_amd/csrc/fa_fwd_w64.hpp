@@ -462,6 +462,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[z][eb][i] = 0.f;
     float m2[2] = {-INFINITY, -INFINITY}, mt[2] = {-INFINITY, -INFINITY};
+    float mbase[2] = {0.f, 0.f};                             // the finite part of m2 (0 while no key has been seen): kept, not re-derived per tile
     float lp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};               // row sums (VALU form): two chains per query block
     f32x16 lacc[2];                                          // row sums (matrix-pipe form): every register = sum_k P[k][query]
     frag_t ones;
@@ -556,8 +557,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         const float lim = (kGeneral && !live) ? -INFINITY : INFINITY;          // scalar select
 #pragma unroll
         for (int z = 0; z < 2; ++z) {
-            const float base = (kPre && m2[z] != -INFINITY) ? m2[z] : 0.f;      // what the tile's logits have subtracted
-            float mabs = kPre ? mx[z] + base : mx[z];
+            float mabs = kPre ? mx[z] + mbase[z] : mx[z];                    // mbase: what the tile's logits have subtracted
             if constexpr (kGeneral) mabs = fminf(mabs, lim);
             mt[z] = fmaxf(mt[z], mabs);
             any = any || (mabs > m2[z] + kThr);
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     auto rescale = [&](const float (&mx)[2], f32x16 (&sc)[2][KB], bool first) {
 #pragma unroll
         for (int z = 0; z < 2; ++z) {
-            const float base0 = (kPre && m2[z] != -INFINITY) ? m2[z] : 0.f;
+            const float base0 = kPre ? mbase[z] : 0.f;
             const float mabs = kPre ? mx[z] + base0 : mx[z];
             const bool up = mabs > m2[z] + kThr;
             const float mn = up ? mabs : m2[z];
@@ -605,6 +605,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                 for (int i = 0; i < 16; ++i) negm[z][i] = -nbase;
             }
             m2[z] = mn;
+            mbase[z] = mn != -INFINITY ? mn : 0.f;
         }
         if constexpr (kPre) fence_valu_operand(negm[0], negm[1]);
     };
