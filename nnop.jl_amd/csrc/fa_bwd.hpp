@@ -48,9 +48,10 @@ struct BwdParams {
     void *dq, *dk, *dv, *dpair;
     const void *d_o, *o, *ms, *ls, *q, *k, *v, *pair;
     const uint8_t* kpad;
-    float* nl;       // [B][QH][QL]  -(ms*log2e + log2(ls)) / (scale*log2e);  -inf for dead rows
-    float* delta;    // [B][QH][QL]  sum_e dO*o
+    float* nl;       // [B][QH][QLs]  -(ms*log2e + log2(ls)) / (scale*log2e);  -inf for dead rows
+    float* delta;    // [B][QH][QLs]  MINUS sum_e dO*o (the initial accumulator of dP); the plain-HIP kernels of fa_generic.hpp keep +delta here
     int   QL, KL, QH, KH, B, causal;
+    int   QLs;       // row stride of nl / delta per (batch, q-head): QL rounded up to 64; the padding holds nl = -inf, delta = 0
     int   n_blk;     // blocks along the workgroup's sequence axis
     int   n_wg;
     float scale;
@@ -66,12 +67,18 @@ struct BwdParams {
 // -------------------------------------------------------------------------------------------------
 template <typename T, int E>
 __global__ __launch_bounds__(256) void fa_bwd_pre_kernel(const BwdParams p, long long n_rows) {
+    // n_rows counts PADDED rows (B * QH * QLs): the rows QL .. QLs-1 of every (batch, head) get nl = -inf, delta = 0, so that
+    // the 64-row forms (fa_bwd_w64.hpp) can copy whole steps of row constants without a bounds test.
     constexpr int LPR = E / 8;                       // lanes per row, 8 elements per lane
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long row = gid / LPR;
+    const long long prow = gid / LPR;
     const int sub = (int)(gid % LPR);
+    const long long bh = (long long)((unsigned)prow / (unsigned)p.QLs);          // padded rows < 2^31 (launcher)
+    const int qi = (int)(prow - bh * p.QLs);
+    const bool live = prow < n_rows && qi < p.QL;
+    const long long row = bh * p.QL + qi;            // row of the dense tensors
     float acc = 0.f;
-    if (row < n_rows) {
+    if (live) {
         typedef T t8 __attribute__((ext_vector_type(8)));
         const t8 a = *reinterpret_cast<const t8*>((const T*)p.d_o + row * E + sub * 8);
         const t8 b = *reinterpret_cast<const t8*>((const T*)p.o + row * E + sub * 8);
@@ -80,18 +87,21 @@ __global__ __launch_bounds__(256) void fa_bwd_pre_kernel(const BwdParams p, long
     }
 #pragma unroll
     for (int off = LPR / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-    if (row < n_rows && sub == 0) {
-        const float m = to_f32(((const T*)p.ms)[row]);
-        const float l = to_f32(((const T*)p.ls)[row]);
-        const float c2 = p.scale * kLog2e;
-        float nl = -(m * kLog2e + __builtin_amdgcn_logf(l)) / c2;   // v_log_f32 = log2
-        float dl = acc;
-        if (!(l > 0.f) || !(nl == nl) || m == -INFINITY) {           // row with no visible key
-            nl = -INFINITY;
-            dl = 0.f;
+    if (prow < n_rows && sub == 0) {
+        float nl = -INFINITY, dl = 0.f;
+        if (live) {
+            const float m = to_f32(((const T*)p.ms)[row]);
+            const float l = to_f32(((const T*)p.ls)[row]);
+            const float c2 = p.scale * kLog2e;
+            nl = -(m * kLog2e + __builtin_amdgcn_logf(l)) / c2;   // v_log_f32 = log2
+            dl = acc;
+            if (!(l > 0.f) || !(nl == nl) || m == -INFINITY) {           // row with no visible key
+                nl = -INFINITY;
+                dl = 0.f;
+            }
         }
-        p.nl[row] = nl;
-        p.delta[row] = dl;
+        p.nl[prow] = nl;
+        p.delta[prow] = -dl;                         // as the kernels consume it: dP' = dO V^T - delta
     }
 }
 
@@ -259,11 +269,12 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         const int g = it / nqt, qt = qt0 + it - g * nqt;
         const int qh = kvh * rep + g;
         const size_t row0 = (size_t)(b * p.QH + qh) * p.QL + (size_t)qt * BQ;
+        const size_t rc0 = (size_t)(b * p.QH + qh) * p.QLs + (size_t)qt * BQ;
         sq.load((const T*)p.q + row0 * E, p.QL - qt * BQ, tid);
         sdo.load((const T*)p.d_o + row0 * E, p.QL - qt * BQ, tid);
         const int last = p.QL - 1 - qt * BQ;               // last existing row of this tile (>= 0)
         rowc_in = rowc_rr <= last;
-        rowc_raw = rowc_src[row0 + (rowc_in ? rowc_rr : last)];
+        rowc_raw = rowc_src[rc0 + (rowc_in ? rowc_rr : last)];
     };
     auto stage_write = [&](char* buf) {
         sq.template write<Row>(buf, tid);
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             sdo.template write<Col>(buf + QIMG + Row::bytes(BQ), tid);
         }
         if (tid < 2 * BQ) {
-            const float rowc = tid < BQ ? (rowc_in ? rowc_raw : -INFINITY) : (rowc_in ? -rowc_raw : 0.f);
+            const float rowc = tid < BQ ? (rowc_in ? rowc_raw : -INFINITY) : (rowc_in ? rowc_raw : 0.f);
             reinterpret_cast<float*>(buf + 2 * QIMG)[tid] = rowc;
         }
     };
@@ -517,8 +528,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         }
     }
 
-    const float nlq = qi < p.QL ? p.nl[(size_t)bh * p.QL + qi] : -INFINITY;
-    const float ndl = qi < p.QL ? -p.delta[(size_t)bh * p.QL + qi] : 0.f;
+    const float nlq = qi < p.QL ? p.nl[(size_t)bh * p.QLs + qi] : -INFINITY;
+    const float ndl = qi < p.QL ? p.delta[(size_t)bh * p.QLs + qi] : 0.f;
 
     frag_t qf[kQRegs ? KS : 1], dof[kQRegs ? KS : 1];
     char* qimg = smem;

@@ -4,6 +4,7 @@
 // scratch from the caller's workspace, dpair zero-filled only when a pair bias is given.
 #pragma once
 #include "fa_bwd.hpp"
+#include "fa_bwd_w64.hpp"
 #include "fa_launch.hpp"
 #include "fa_generic.hpp"
 #include <math.h>
@@ -58,6 +59,39 @@ static int launch_dq(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
     return NNOP_OK;
 }
 
+// The one-wave-per-SIMD form (fa_bwd_w64.hpp): KIND = kBwdDKDV / kBwdDQ
+template <typename T, int E, int KIND, int MODE>
+static int launch_bwd_w64(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
+    using SH = BwdW64Shape<E, KIND>;
+    constexpr int lds = fa_bwd_w64_lds_bytes<T, E, KIND>(MODE != 0);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fa_bwd_w64_kernel<T, E, KIND, MODE>;
+    static unsigned long long lds_done = 0;
+    if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
+    BwdParams pk = p;
+    const int len = KIND == kBwdDQ ? d.ql : d.kl, hd = KIND == kBwdDQ ? d.qh : d.kh;
+    pk.n_blk = (len + SH::WG_ROWS - 1) / SH::WG_ROWS;
+    const long long n_wg = (long long)pk.n_blk * hd * d.batch;
+    if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    pk.n_wg = (int)n_wg;
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds, s, pk);
+    return NNOP_OK;
+}
+// Is the 64-row form instantiated for this problem, and do its 32-bit descriptor ranges hold it?
+template <typename T, int E> static bool bwd_w64_ok(const nnop_fa_desc& d, int kind) {
+    if constexpr (sizeof(T) != 2 || (E != 64 && E != 128)) return false;
+    else {
+        const long long rb = 2LL * E;
+        if (kind == kBwdDKDV) {
+            // one descriptor spans the q-heads of a kv head; the row constants of the whole launch behind another
+            if ((long long)(d.qh / d.kh) * d.ql * rb >= (1LL << 32)) return false;
+            if (2LL * d.batch * d.qh * ((d.ql + 63) & ~63) * 4 >= (1LL << 32)) return false;
+            return true;
+        }
+        return (long long)d.kl * rb < (1LL << 32) && d.kl <= 64 * kMaxMaskTiles;
+    }
+}
+
 template <typename T, int E, int MODE>
 static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
     using C = BwdCfg<T, E>;
@@ -65,7 +99,9 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     p.dq = a.dq; p.dk = a.dk; p.dv = a.dv; p.dpair = a.pair ? a.dpair : nullptr;
     p.d_o = a.d_o; p.o = a.o; p.ms = a.ms; p.ls = a.ls;
     p.q = a.q; p.k = a.k; p.v = a.v; p.pair = a.pair; p.kpad = a.kpad;
-    const long long n_rows = (long long)d.batch * d.qh * d.ql;
+    p.QLs = (d.ql + 63) & ~63;
+    const long long n_rows = (long long)d.batch * d.qh * p.QLs;            // padded rows (bwd_workspace_bytes)
+    if (n_rows > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.nl = (float*)a.workspace;
     p.delta = p.nl + n_rows;
     p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
@@ -102,17 +138,30 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     // workgroups of the 7 / 8-wave E = 128 forms from which they are used: one per CU when every block has the same work,
     // two per CU under a causal mask (measured, tools/bwd_ab.py: 256 blocks non-causal +27 %, causal -9 %)
     const int big_thr = big_tune >= 0 ? big_tune : (d.causal ? 512 : 256);
+    // the one-wave-per-SIMD form (fa_bwd_w64.hpp): 16-bit, E = 64 / 128, plain / masked modes.  NNOP_BWD_W64: 0 never, 1 both
+    // passes wherever instantiated, 2 dK/dV only, 3 dQ only; automatic: wherever instantiated
+    const int w64_tune = tune_get(kTuneBwdW64);
+    bool w64_kv = false, w64_q = false;
+    if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {
+        const bool want_kv = w64_tune < 0 || w64_tune == 1 || w64_tune == 2;
+        const bool want_q = w64_tune < 0 || w64_tune == 1 || w64_tune == 3;
+        w64_kv = want_kv && bwd_w64_ok<T, E>(d, kBwdDKDV);
+        w64_q = want_q && bwd_w64_ok<T, E>(d, kBwdDQ);
+    }
     // 3. dK, dV
     {
         int st = NNOP_OK;
         bool done = false;
-        if constexpr (C::kBig7) {
+        if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {
+            if (w64_kv) { st = launch_bwd_w64<T, E, kBwdDKDV, MODE>(d, p, s); done = true; }
+        }
+        if constexpr (C::kBig7) if (!done) {
             // 8 waves double-buffered where K lives in registers (64 KiB of V images + 2 x 32 KiB of tiles), else 7 single-buffered
             constexpr int NWB = fa_bwd_dkdv_kregs<T, E, MODE>() ? 8 : 7;
             const long long nb = (long long)((d.kl + 32 * NWB - 1) / (32 * NWB)) * d.kh * d.batch;
             if (nb >= big_thr) { st = launch_dkdv<T, E, NWB, C::BQ, MODE>(d, p, s); done = true; }
         }
-        if constexpr (C::kWide8) {
+        if constexpr (C::kWide8) if (!done) {
             const long long n8 = (long long)((d.kl + 255) / 256) * d.kh * d.batch;
             const int nw = tune_get(kTuneBwdNW);
             if (MODE != 2 && (nw == 8 || nw == 81 || (nw < 0 && !d.causal && n8 >= 256))) { st = launch_dkdv<T, E, 8, C::BQ, MODE>(d, p, s); done = true; }
@@ -124,13 +173,21 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     {
         int st = NNOP_OK;
         bool done = false;
-        if constexpr (C::kBig7) {
+        if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {
+            // plain mode needs whole steps of keys; a ragged KL takes the masked kernel
+            if (w64_q) {
+                if (MODE == 0 && (d.kl & 31) != 0) st = launch_bwd_w64<T, E, kBwdDQ, 1>(d, p, s);
+                else st = launch_bwd_w64<T, E, kBwdDQ, MODE>(d, p, s);
+                done = true;
+            }
+        }
+        if constexpr (C::kBig7) if (!done) {
             // 8 waves where Q, dO live in registers (no LDS images of them: double-buffered tiles fit), else 7 single-buffered
             constexpr int NWB = fa_bwd_dq_qregs<T, E, MODE>() ? 8 : 7;
             const long long nb = (long long)((d.ql + 32 * NWB - 1) / (32 * NWB)) * d.qh * d.batch;
             if (nb >= big_thr) { st = launch_dq<T, E, NWB, C::BK, MODE>(d, p, s); done = true; }
         }
-        if constexpr (C::kWide8) {
+        if constexpr (C::kWide8) if (!done) {
             const long long n8 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
             const int nw = tune_get(kTuneBwdNW);
             if (MODE != 2 && (nw == 8 || nw == 82 || (nw < 0 && !d.causal && n8 >= 256))) { st = launch_dq<T, E, 8, C::BK, MODE>(d, p, s); done = true; }
@@ -167,6 +224,7 @@ template <typename T> static int launch_bwd_generic(const nnop_fa_desc& d, const
     p.d_o = a.d_o; p.o = a.o; p.ms = a.ms; p.ls = a.ls;
     p.q = a.q; p.k = a.k; p.v = a.v; p.pair = a.pair; p.kpad = a.kpad;
     const long long n_rows = (long long)d.batch * d.qh * d.ql, n_krows = (long long)d.batch * d.kh * d.kl;
+    p.QLs = d.ql;                                                          // dense rows here
     p.nl = (float*)a.workspace;
     p.delta = p.nl + n_rows;
     p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;

@@ -1,0 +1,784 @@
+// fa_bwd_w64.hpp -- backward kernels in the forward's "one wave per SIMD" form (16-bit types, E = 64 / 128, no pair bias).
+//
+// What `_flash_attention_bwd!` computes (src/attention_bwd.jl:1-161), as the same two passes as fa_bwd.hpp (dK/dV with the key
+// block stationary, dQ with the query block stationary: no atomics, GQA included, bitwise reproducible), but both passes are ONE
+// kernel template here, because they are the same program with the roles of the two sequence axes exchanged:
+//
+//   a wave keeps "stationary" rows (KIND dK/dV: keys, KIND dQ: queries) for the whole kernel -- their fragments of the two
+//   operand tensors (K, V / Q, dO) and their gradient accumulators (dK^T, dV^T / dQ^T), all in the ACCUMULATOR file -- while the
+//   workgroup streams tiles of the other axis (Q, dO / K, V) through an LDS ring:
+//
+//     X products   S [t][s] = T1 rows . B1 (+ row constants)      dP [t][s] = T2 rows . B2 (- delta)
+//                  A = a row fragment of the streamed tile (LDS, ds_read_b128), B = a stationary fragment (accumulator file):
+//                  the streamed index lands in the accumulator REGISTERS, the stationary one on the LANE
+//     softmax'     P = exp2(c S'),  dS = P dP'      (the forward's residuals are folded into S' and dP': no row max, no sum)
+//     Y products   acc^T[e][s] += T^T[e][t] . F[t][s]   for (dV: T = dO, F = P), (dK: T = Q, F = dS)  /  (dQ: T = K, F = dS)
+//                  A = a COLUMN fragment of the streamed tile (ds_read_b64_tr_b16), B = P / dS straight from the registers of the
+//                  X products (accumulator-as-operand: no lane movement, no LDS)
+//
+//   * one wave per SIMD owning the whole 512-register file; every MFMA is inline asm with explicit register classes and the
+//     loop body is HAND-PLACED slot by slot (sched_barrier pins), as in fa_fwd_w64.hpp -- hipcc neither splits the two files
+//     that way nor interleaves asm MFMAs with VALU work on its own.
+//   * the streamed tiles arrive by LDS-DMA into ONE dual-use image per tensor (DualImg: row reads and transposed column
+//     reads both conflict-free, tools/dual_image.py), ring of 4 slots, a batch stays in flight for two iterations (counted
+//     vmcnt), one barrier per iteration.
+//   * three-stage software pipeline over the streamed steps: iteration u runs Y(u-1), then X(u+1), with the element-wise work of
+//     step u dealt out over all of their MFMA slots by issue cost.  The three stages touch disjoint registers (two sets of
+//     score tiles, two sets of P / dS fragments), so nothing inside an iteration waits for anything else inside it.
+//   * wave shapes (ZS stationary 32-row blocks per wave x ZT streamed 32-row blocks per step, ZS ZT = 2 so that a step is two
+//     score tiles): dK/dV E = 64: 2 x 1 (64 keys per wave: each streamed fragment feeds two MFMAs), E = 128: 1 x 2 (the
+//     accumulators of 64 keys would be the whole accumulator file); dQ: 2 x 1.
+//
+// Modes: 0 plain / 1 masked (causal, key padding, ragged streamed length).  The pair-bias modes stay on fa_bwd.hpp.
+#pragma once
+#include "fa_bwd.hpp"
+#include "fa_fwd_w64.hpp"
+
+// diagnostic (make DEV=1 VAR=-DNNOP_BW64_STAMP=1; results WRONG by construction): s_memtime stamps, see tools/bw64_stamp.py
+#if !defined(NNOP_DEV_BUILD)
+#undef NNOP_BW64_STAMP
+#endif
+#ifndef NNOP_BW64_STAMP
+#define NNOP_BW64_STAMP 0
+#endif
+#ifndef NNOP_BW64_LAG
+#define NNOP_BW64_LAG 3
+#endif
+#ifndef NNOP_BW64_PF
+#define NNOP_BW64_PF 3
+#endif
+
+namespace nnop {
+
+enum : int { kBwdDKDV = 0, kBwdDQ = 1 };
+
+// ---- DualImg: one LDS copy of a [rows][E] 16-bit tile for row reads AND transposed column reads -----------------------------
+// Row-major with the 16-byte chunks of a row XOR-swizzled so that BOTH MFMA operand reads are bank-conflict free:
+//   row read    (ds_read_b128, four 16-lane groups of distinct rows mod 16): x(row) must be a bijection of row & 15;
+//   column read (ds_read_b64_tr_b16, per 32-lane half: 4 consecutive rows x 64 bytes): the four rows must land in four different
+//               64-byte bank groups -- which the row swizzles of RowImg (row & 15, (row >> 1) & 7) do not give (4-way conflict).
+// E = 128 (256-byte rows): x = ((row & 3) << 2) | ((row >> 2) & 3)      (the guide's layout (b))
+// E =  64 (128-byte rows, two rows per bank row): x = bit1 << 2 | bit3 << 1 | bit2 of row
+// tools/dual_image.py restates every formula below on the CPU and checks data mapping and bank conflicts (tests/test_dual_image.py).
+template <typename T, int E> struct DualImg {
+    static_assert(sizeof(T) == 2 && (E == 64 || E == 128), "16-bit element types, E = 64 or 128");
+    static constexpr int kRowBytes = 2 * E;
+    static constexpr int bytes(int rows) { return rows * kRowBytes; }
+    NNOP_DEV static constexpr int xor_of(int row) {
+        if constexpr (E == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
+        else return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1);
+    }
+    // LDS-DMA: source byte (inside the dense tile) of the 16 bytes that land at image byte `o` (the destination is lane-linear)
+    NNOP_DEV static int src_of(int o) {
+        const int row = o / kRowBytes, phys = (o % kRowBytes) >> 4;
+        return row * kRowBytes + ((phys ^ xor_of(row)) << 4);
+    }
+    // row read of lane (r, h), 32-row block zb, contraction step ks:  (row_lane_base ^ (ks << 5)) + zb * 32 * kRowBytes
+    NNOP_DEV static int row_lane_base(int lane) {
+        const int r = lane & 31, h = lane >> 5;
+        return r * kRowBytes + ((xor_of(r) ^ h) << 4);
+    }
+    // column read, 16-row step kk, 32-column block eb, half s:  (col_lane_base ^ (eb << 6) ^ (s << 5)) + (16 kk + 8 s) * kRowBytes
+    NNOP_DEV static int col_lane_base(int lane) {
+        const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+        const int qx = E == 128 ? q : (q >> 1);
+        return (4 * h + q) * kRowBytes + 16 * (4 * qx + ((2 * g1 + (p >> 1)) ^ h)) + 8 * (p & 1);
+    }
+};
+
+// ---- shapes -------------------------------------------------------------------------------------------------------------------
+template <int E, int KIND> struct BwdW64Shape {
+    static constexpr bool kDQ = KIND == kBwdDQ;
+    static constexpr int ZS = (kDQ || E == 64) ? 2 : 1;       // stationary 32-row blocks per wave
+    static constexpr int ZT = 2 / ZS;                         // streamed 32-row blocks per step
+    static constexpr int NYP = kDQ ? 1 : 2;                   // Y products
+    static constexpr int KS = E / 16, EB = E / 32;
+    static constexpr int RT = 32 * ZT, SW = 32 * ZS, RB = 2 * E;
+    static constexpr int IMG = RT * RB;                       // one streamed tile image
+    static constexpr int RC = kDQ ? 0 : 512;                  // row constants of a step: nl[64], -delta[64] (fp32)
+    static constexpr int SLOT = 2 * IMG + RC, NS = 4;
+    static constexpr int NJ = IMG / 4096;                     // LDS-DMA pieces per wave, tile and tensor
+    static constexpr int NPB = 2 * NJ + (kDQ ? 0 : 1);        // DMA instructions per wave and step
+    static constexpr int NFY = NYP * 2 * ZT * EB, NFX = 2 * ZT * KS, NF = NFY + NFX;    // A-fragment stream of an iteration
+    static constexpr int NY = NFY * ZS, NX = NFX * ZS, NSLOT = NY + NX;               // MFMA slots
+    static constexpr int WG_ROWS = 4 * SW;
+    static_assert(IMG % 4096 == 0 && NJ >= 1 && NJ <= 4, "four waves x NJ pieces = one image; 12-bit immediate");
+};
+template <typename T, int E, int KIND> constexpr int fa_bwd_w64_lds_bytes(bool masked) {
+    using SH = BwdW64Shape<E, KIND>;
+    return SH::NS * SH::SLOT + (masked ? (SH::kDQ ? 16 + 8 * kMaxMaskTiles : 16) : 0);
+}
+
+// ---- the slot plan ------------------------------------------------------------------------------------------------------------
+// An iteration is NSLOT slots of one MFMA each: Y(u-1) first, then X(u+1).  Besides its MFMA a slot carries fixed work (fragment
+// read-ahead, row-constant reads, an LDS-DMA piece, the barrier) and a share of the element-wise stream of step u: step n issues
+// part A of element n (scale, v_exp_f32) and part B of element n - LAG (dS = P dP' and, for an odd element, the 16-bit converts
+// of the pair it closes).  No step depends on anything else in the iteration, so the stream is dealt out by issue cost alone:
+// the smallest per-slot budget for which a greedy in-order fill places everything (costs as in W64Plan).  Slot 0 takes no
+// movable work: it carries the iteration's bookkeeping, and the tiles written by the last MFMAs of the previous iteration are
+// not read before two MFMA slots have passed.
+template <int E, int KIND, bool MASKED, int LAG, int PF> struct BwdW64Plan {
+    using SH = BwdW64Shape<E, KIND>;
+    static constexpr int NSLOT = SH::NSLOT, NEL = 32, NSTEP = NEL + LAG;
+    static constexpr int BAR_SLOT = (SH::NFY - PF) * SH::ZS;  // the barrier opens this slot (all column reads of Y are issued)
+    static constexpr int FIRST = 1;                           // first slot with movable work
+    int st_end[NSLOT] = {};
+    int cost[NSLOT] = {};
+    int cap = 0;
+
+    static constexpr int dma_slot(int d) { return BAR_SLOT + 1 + 2 * d; }          // piece d of the batch: one per second slot
+    static constexpr int fixed_cost(int s) {
+        int c = 0;
+        if (s % SH::ZS == 0) c += 8;                          // fragment read-ahead (one ds_read_b128 or two transposed reads)
+        if (s == 0) c += 40;                                  // ring rotation, image bases, step counters, mask test
+        if (s == BAR_SLOT) c += 16;
+        if (s == BAR_SLOT + 1) c += 24;                       // scalar address arithmetic of the batch
+        for (int d = 0; d < SH::NPB; ++d)
+            if (s == dma_slot(d)) c += 24;
+        if (!SH::kDQ && s >= BAR_SLOT && s < SH::NY + SH::NX / 2 + SH::ZS * SH::KS) c += 4;   // row-constant reads (spread)
+        return c;
+    }
+    static constexpr int step_cost(int n) {
+        int c = n < NEL ? 12 : 0;
+        const int m = n - LAG;
+        if (m >= 0) c += 4 + ((m & 1) ? 4 * SH::NYP : 0);
+        return c;
+    }
+    constexpr bool fill(int budget) {
+        int n = 0;
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            int used = fixed_cost(sl);
+            if (sl >= FIRST)
+                while (n < NSTEP && used + step_cost(n) <= budget) used += step_cost(n++);
+            st_end[sl] = n;
+            cost[sl] = used;
+        }
+        cap = budget;
+        return n == NSTEP;
+    }
+    static constexpr BwdW64Plan make() {
+        BwdW64Plan pl{};
+        for (int b = 8; b <= 160; b += 2)
+            if (pl.fill(b)) break;
+        return pl;
+    }
+};
+
+// LDS-DMA of 64 consecutive dwords (a step's row constants): lane l copies 4 bytes from base + soffset + 4 l to M0 + 4 l
+NNOP_DEV void dma_dwords(u32x4 rsrc, uint32_t voff, uint32_t soff, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+
+// 32 x E transposed accumulator tiles (rows = embedding in the registers, column = this lane's sequence row) -> one row of a
+// [rows][E] tensor, 16-byte stores (lane halves paired with v_permlane32_swap, as the forward's epilogue)
+template <typename T, int EB> NNOP_DEV void store_acc_row16(T* rowp, f32x16 (&acc)[EB], float mul, int h, bool ok) {
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb) {
+        fence_acc_result(acc[eb]);
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            typedef T t4 __attribute__((ext_vector_type(4)));
+            const f32x4 w = {acc[eb][4 * g] * mul, acc[eb][4 * g + 1] * mul, acc[eb][4 * g + 2] * mul, acc[eb][4 * g + 3] * mul};
+            const u32x2 u = __builtin_bit_cast(u32x2, __builtin_convertvector(w, t4));
+            pk[g][0] = u[0];
+            pk[g][1] = u[1];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+            const u32x4 lo = {s0[0], s1[0], s0[1], s1[1]};
+            if (ok) *reinterpret_cast<u32x4*>(rowp + 32 * eb + 8 * g + 8 * h) = lo;
+        }
+    }
+}
+
+template <typename T, int E, int KIND, int MODE>
+__global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
+    using SH = BwdW64Shape<E, KIND>;
+    using frag_t = typename Elem<T>::frag;
+    using Img = DualImg<T, E>;
+    using MM = MfmaAsm<T>;
+    constexpr bool kDQ = SH::kDQ, kGeneral = MODE != 0;
+    constexpr int ZS = SH::ZS, ZT = SH::ZT, NYP = SH::NYP, KS = SH::KS, EB = SH::EB;
+    constexpr int RT = SH::RT, SW = SH::SW, RB = SH::RB, IMG = SH::IMG, SLOT = SH::SLOT, NS = SH::NS, NJ = SH::NJ, NPB = SH::NPB;
+    constexpr int NFY = SH::NFY, NF = SH::NF, NY = SH::NY, NX = SH::NX, NSLOT = SH::NSLOT;
+    constexpr int PF = NNOP_BW64_PF, RF = 4, LAG = NNOP_BW64_LAG;
+    static_assert(NF % RF == 0 && PF < RF && PF < NFY, "static fragment ring; the barrier sits inside phase Y");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#if NNOP_BW64_STAMP
+    uint64_t stamp[6];
+    stamp[0] = __builtin_amdgcn_s_memtime();
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const float c2 = p.scale * kLog2e;
+    const int rep = p.QH / p.KH;
+
+    // ---- which block; the stationary rows of this wave; the streamed sequence ------------------------------------------------
+    int b, kvh, bh_s;                  // bh_s: (batch, head) index of the stationary tensors
+    int s0wg;                          // first stationary row of the workgroup
+    int SL, TL;                        // stationary / streamed sequence lengths
+    int heads, u0 = 0, nps;            // streamed heads (dK/dV under GQA), first step, steps per head
+    if constexpr (kDQ) {
+        const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk * rep);
+        int blk = lin % p.n_blk;
+        bh_s = lin / p.n_blk;
+        if (kGeneral && p.causal) blk = p.n_blk - 1 - blk;                 // heaviest query blocks first
+        b = bh_s / p.QH;
+        kvh = (bh_s - b * p.QH) / rep;
+        s0wg = blk * SH::WG_ROWS;
+        SL = p.QL; TL = p.KL; heads = 1;
+        nps = (TL + RT - 1) / RT;
+        if (kGeneral && p.causal) {
+            int last = s0wg + SH::WG_ROWS - 1;
+            if (last > SL - 1) last = SL - 1;
+            const int t_c = last / RT + 1;
+            if (t_c < nps) nps = t_c;
+        }
+    } else {
+        const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk);
+        const int blk = lin % p.n_blk;
+        bh_s = lin / p.n_blk;
+        b = bh_s / p.KH;
+        kvh = bh_s - b * p.KH;
+        s0wg = blk * SH::WG_ROWS;
+        SL = p.KL; TL = p.QL; heads = rep;
+        const int nst = (TL + RT - 1) / RT;
+        if (kGeneral && p.causal) u0 = s0wg / RT < nst ? s0wg / RT : nst;   // queries in front of the block's first key see none of it
+        nps = nst - u0;
+    }
+    const int s0w = s0wg + wave * SW;
+    int sidx[ZS], sidx_c[ZS];
+#pragma unroll
+    for (int zs = 0; zs < ZS; ++zs) {
+        sidx[zs] = s0w + 32 * zs + r;
+        sidx_c[zs] = sidx[zs] < SL ? sidx[zs] : SL - 1;
+    }
+
+    const T* __restrict__ b1p;         // stationary operand of S  (dK/dV: K, dQ: Q)
+    const T* __restrict__ b2p;         // stationary operand of dP (dK/dV: V, dQ: dO)
+    const char* __restrict__ t1p;      // streamed tensor read by rows for S  and by columns for dK / dQ  (dK/dV: Q, dQ: K)
+    const char* __restrict__ t2p;      // streamed tensor read by rows for dP and by columns for dV       (dK/dV: dO, dQ: V)
+    uint32_t t_bytes;
+    if constexpr (kDQ) {
+        b1p = (const T*)p.q + (size_t)bh_s * p.QL * E;
+        b2p = (const T*)p.d_o + (size_t)bh_s * p.QL * E;
+        t1p = (const char*)((const T*)p.k + (size_t)(b * p.KH + kvh) * p.KL * E);
+        t2p = (const char*)((const T*)p.v + (size_t)(b * p.KH + kvh) * p.KL * E);
+        t_bytes = (uint32_t)p.KL * (uint32_t)RB;
+    } else {
+        b1p = (const T*)p.k + (size_t)bh_s * p.KL * E;
+        b2p = (const T*)p.v + (size_t)bh_s * p.KL * E;
+        const size_t g0 = (size_t)(b * p.QH + kvh * rep) * p.QL * E;       // the group's q-heads are contiguous
+        t1p = (const char*)((const T*)p.q + g0);
+        t2p = (const char*)((const T*)p.d_o + g0);
+        t_bytes = (uint32_t)rep * (uint32_t)p.QL * (uint32_t)RB;           // < 4 GiB (launcher)
+    }
+    const int U = heads * nps;                                             // streamed steps of this workgroup
+
+    // key padding, dK/dV: a key block with no valid key gets dK = dV = 0 and does no work; dQ: validity words in LDS
+    const uint8_t* __restrict__ mp = kGeneral && p.kpad ? p.kpad + (size_t)b * p.KL : nullptr;
+    bool svalid[ZS];
+#pragma unroll
+    for (int zs = 0; zs < ZS; ++zs) svalid[zs] = sidx[zs] < SL;
+    uint64_t* const vbits = reinterpret_cast<uint64_t*>(smem + NS * SLOT + 16);
+    int n_steps = U;
+    if constexpr (kGeneral && !kDQ) {
+        if (mp) {
+            bool any = false;
+#pragma unroll
+            for (int zs = 0; zs < ZS; ++zs) {
+                if (svalid[zs]) svalid[zs] = mp[sidx[zs]] != 0;
+                any = any || svalid[zs];
+            }
+            // (no __syncthreads_or: its static LDS word would sit in front of the dynamic segment, whose base the XOR-addressed
+            // fragment reads need 256-byte aligned)
+            int* flag = reinterpret_cast<int*>(smem + NS * SLOT);
+            if (tid == 0) *flag = 0;
+            __syncthreads();
+            if (any) *flag = 1;
+            __syncthreads();
+            if (*flag == 0) n_steps = 0;
+        }
+    }
+    if constexpr (kGeneral && kDQ) {
+        int* slot = reinterpret_cast<int*>(smem + NS * SLOT);
+        const int nk = n_steps * RT < p.KL ? n_steps * RT : p.KL;
+        if (mp) {
+            const int last = kpad_scan(mp, p.KL, nk, vbits, kMaxMaskTiles, slot, tid, 256);
+            const int t_m = last / RT + 1;
+            if (t_m < n_steps) n_steps = t_m;
+        } else {
+            for (int w = tid; w * 64 < nk; w += 256) {
+                const int left = p.KL - w * 64;
+                vbits[w] = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- accumulators, stationary fragments (accumulator file) ---------------------------------------------------------------
+    f32x16 acc[NYP][ZS][EB];
+#pragma unroll
+    for (int y = 0; y < NYP; ++y)
+#pragma unroll
+        for (int zs = 0; zs < ZS; ++zs)
+#pragma unroll
+            for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[y][zs][eb][i] = 0.f;
+
+    if (n_steps > 0) {
+        const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+        // ragged streamed length: rows of the last step past the end are outside the descriptor's range.  Whatever the DMA does
+        // with such a lane (zeros, or nothing), the ring must hold finite data there: they are multiplied by P = 0 / dS = 0.
+        if ((TL & (RT - 1)) != 0) {
+            for (int i = tid * 16; i < NS * SLOT; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+            __syncthreads();
+        }
+        // ---- LDS-DMA: per-lane source offsets (the image's layout applied to the SOURCE), descriptors, step offsets -----------
+        // wave w copies image bytes [NJ KiB * w, NJ KiB * (w + 1)) of both tensors; voff[j] = source byte of its chunk of piece j
+        // MINUS 1024 j (the load's immediate adds it back on both sides).
+        uint32_t voff[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) voff[j] = (uint32_t)(Img::src_of((wave * NJ + j) * 1024 + lane * 16) - j * 1024);
+        const uint32_t wave_off = (uint32_t)(wave * NJ * 1024);
+        const u32x4 rs1 = make_rsrc(t1p, t_bytes), rs2 = make_rsrc(t2p, t_bytes);
+        // row constants (dK/dV): nl / delta rows of the workspace, [B][QH][QLs] each (QLs = QL rounded up to 64: the padding holds
+        // nl = -inf, delta = 0, so a row past QL gives P = 0 whatever its Q / dO rows hold); even waves copy nl, odd waves delta
+        u32x4 rsc = rs1;
+        uint32_t rc_voff = 0, rc_dst_off = 0;
+        const uint32_t rc_head = (uint32_t)p.QLs * 4u;
+        if constexpr (!kDQ) {
+            const size_t rows_all = (size_t)p.B * p.QH * p.QLs;
+            rsc = make_rsrc(p.nl, (uint32_t)(2 * rows_all * 4));
+            rc_voff = (uint32_t)lane * 4u + ((wave & 1) ? (uint32_t)(rows_all * 4) : 0u);
+            rc_dst_off = 2 * IMG + ((wave & 1) ? 256u : 0u);
+        }
+        // running (head, step) of the NEXT step to copy, clamped to the last one (copied again into a slot nobody reads)
+        int d_it = 0, d_s = 0, d_g = 0;
+        uint32_t d_off = (uint32_t)u0 * (uint32_t)(RT * RB);
+        uint32_t d_rc = kDQ ? 0u : ((uint32_t)((b * p.QH + kvh * rep)) * rc_head + (uint32_t)(u0 * RT) * 4u);
+        const uint32_t rc_group = d_rc;
+        auto advance_dma = [&]() {
+            if (d_it + 1 < n_steps) {
+                ++d_it; ++d_s;
+                d_off += (uint32_t)(RT * RB);
+                d_rc += (uint32_t)(RT * 4);
+                if constexpr (!kDQ) {
+                    if (d_s == nps) {
+                        d_s = 0; ++d_g;
+                        d_off = ((uint32_t)d_g * (uint32_t)p.QL + (uint32_t)(u0 * RT)) * (uint32_t)RB;
+                        d_rc = rc_group + (uint32_t)d_g * rc_head;
+                    }
+                }
+            }
+        };
+        auto issue_step = [&](uint32_t slot) {          // slot: LDS byte address of the ring slot + this wave's share
+            static_for<NJ>([&](auto jc) { constexpr int j = decltype(jc)::value; dma_piece<j, j == 0>(rs1, voff[j], d_off, slot); });
+            static_for<NJ>([&](auto jc) { constexpr int j = decltype(jc)::value; dma_piece<j, j == 0>(rs2, voff[j], d_off, slot + IMG); });
+            if constexpr (!kDQ) dma_dwords(rsc, rc_voff, d_rc, slot - wave_off + rc_dst_off);
+        };
+        // Ring slots as rotating scalars (each = slot address + wave_off):
+        //   sY: step u-1 (column reads of phase Y; free behind the barrier -> target of the next batch), sM: step u,
+        //   sX: step u+1 (row reads of phase X), sF: step u+2 (in flight)
+        uint32_t sM = lds0 + wave_off, sX = sM + SLOT, sF = sM + 2 * SLOT, sY = sM + 3 * SLOT;
+        auto rotate_slots = [&]() { const uint32_t y = sY; sY = sM; sM = sX; sX = sF; sF = y; };
+
+        // ---- prologue: steps 0 (also into the slot phase Y(-1) reads: finite data under zero fragments), 1, 2 in flight ---------
+        issue_step(sM);
+        issue_step(sY);
+        advance_dma();
+        issue_step(sX);
+        advance_dma();
+        issue_step(sF);
+        advance_dma();
+
+        frag_t b1[ZS][KS], b2[ZS][KS];
+#pragma unroll
+        for (int zs = 0; zs < ZS; ++zs)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                b1[zs][ks] = load_q_frag<frag_t>(b1p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
+                b2[zs][ks] = load_q_frag<frag_t>(b2p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
+            }
+        // dQ: the query's row constants are per lane: nl2 = c2 * nl (exponent offset), -delta as the initial accumulator of dP
+        float nl2[ZS];
+        f32x16 ndl[ZS];
+        if constexpr (kDQ) {
+#pragma unroll
+            for (int zs = 0; zs < ZS; ++zs) {
+                const size_t ro = (size_t)bh_s * p.QLs + sidx_c[zs];
+                const float nlv = p.nl[ro], dlv = p.delta[ro];
+                nl2[zs] = sidx[zs] < SL ? nlv * c2 : -INFINITY;            // nl = -inf (dead row) stays -inf: c2 > 0
+                const float nd = sidx[zs] < SL ? dlv : 0.f;                        // the workspace holds -delta
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ndl[zs][i] = nd;
+            }
+            if constexpr (ZS == 2) fence_valu_operand(ndl[0], ndl[1]);
+        }
+
+        // score tiles: two sets (roles swap every iteration), P / dS fragments as words: two sets
+        f32x16 sA[ZS][ZT], dA[ZS][ZT], sB[ZS][ZT], dB[ZS][ZT];
+        u32x4 fA[NYP][ZS][2 * ZT], fB[NYP][ZS][2 * ZT];
+#pragma unroll
+        for (int y = 0; y < NYP; ++y)
+#pragma unroll
+            for (int zs = 0; zs < ZS; ++zs)
+#pragma unroll
+                for (int kk = 0; kk < 2 * ZT; ++kk) { fA[y][zs][kk] = u32x4{0, 0, 0, 0}; fB[y][zs][kk] = u32x4{0, 0, 0, 0}; }
+
+        // ---- LDS reads from integer addresses -----------------------------------------------------------------------------------
+        typedef __attribute__((address_space(3))) const frag_t* lds_frag_p;
+        typedef __attribute__((address_space(3))) s16x4* lds_tr_p;
+        typedef __attribute__((address_space(3))) const f32x4* lds_f4_p;
+        const uint32_t row_lane = (uint32_t)Img::row_lane_base(lane) - wave_off;     // ring scalars include wave_off
+        const uint32_t col_lane = (uint32_t)Img::col_lane_base(lane) - wave_off;
+        const uint32_t rc_lane = (uint32_t)(2 * IMG + 16 * h) - wave_off;
+        auto opaque = [](uint32_t x) { asm volatile("" : "+v"(x)); return x; };
+        auto pin = [](auto& x) { asm volatile("" : "+v"(x)); };
+        // row fragment g of phase X (g = (product * ZT + zt) * KS + ks) from the slot behind `ra` (= slot + row_lane)
+        auto read_row = [&](uint32_t ra, int g) -> frag_t {
+            const int prod = g / (ZT * KS), zt = (g / KS) % ZT, ks = g % KS;
+            return *(lds_frag_p)(uintptr_t)((ra ^ (uint32_t)(ks << 5)) + (uint32_t)(prod * IMG + zt * 32 * RB));
+        };
+        // column fragment f of phase Y (f = (y * 2 ZT + kk) * EB + eb) from the slot behind `ca` (= slot + col_lane)
+        auto read_col = [&](uint32_t ca, int f) -> frag_t {
+            const int y = f / (2 * ZT * EB), kk = (f / EB) % (2 * ZT), eb = f % EB;
+            const int img = kDQ ? 0 : (y == 0 ? IMG : 0);                  // dV: dO columns, dK: Q columns; dQ: K columns
+            const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(uintptr_t)((ca ^ (uint32_t)(eb << 6)) + (uint32_t)(img + 16 * kk * RB)));
+            const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(uintptr_t)((ca ^ (uint32_t)((eb << 6) | 32)) + (uint32_t)(img + (16 * kk + 8) * RB)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 v8 = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+            return __builtin_bit_cast(frag_t, v8);
+        };
+        // a tile written by compiler-visible code (LDS reads, possibly copies) -> C operand of an asm MFMA: 2 wait states
+        auto tile_ready = [](f32x16& t) { asm volatile("s_nop 1" : "+v"(t)); };
+        // dK/dV: initial accumulators of tile (product, zt): row constants of the step's rows 32 zt + acc_row(i, h)
+        auto read_rc = [&](uint32_t ca, int prod, int zt) -> f32x16 {
+            f32x16 t;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 v = *(lds_f4_p)(uintptr_t)(ca + (uint32_t)(prod * 256 + zt * 128 + g4 * 32));
+                t[4 * g4] = v[0]; t[4 * g4 + 1] = v[1]; t[4 * g4 + 2] = v[2]; t[4 * g4 + 3] = v[3];
+            }
+            return t;
+        };
+
+        // ---- masks (masked mode): keep-bits of one score tile per lane, bit lr <-> accumulator register i, lr = acc_row(i, 0) ----
+        // dK/dV (causal): register row = query t0 + 32 zt + lr + 4 h, lane = key: keep iff query >= key
+        // dQ: register row = key t0 + lr + 4 h, lane = query: keep iff the key is valid and key <= query (causal)
+        uint64_t vword_next = 0;
+        auto vword_fetch = [&](int u) { const int w = (u * RT) >> 6; vword_next = vbits[w < kMaxMaskTiles ? w : kMaxMaskTiles - 1]; };
+        auto vword_take = [&](int u) -> uint32_t {
+            const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(vword_next >> 32)) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)vword_next);
+            return (uint32_t)(w >> ((u * RT) & 63));
+        };
+        auto apply_mask = [&](f32x16 (&s)[ZS][ZT], int t0, uint32_t valid) {
+#pragma unroll
+            for (int zs = 0; zs < ZS; ++zs)
+#pragma unroll
+                for (int zt = 0; zt < ZT; ++zt) {
+                    uint32_t m;
+                    if constexpr (kDQ) {
+                        const int lim = (p.causal ? sidx[zs] : 0x3fffffff) - t0 - 4 * h;
+                        const uint32_t cm = lim >= 31 ? ~0u : (lim < 0 ? 0u : ((2u << lim) - 1u));
+                        m = (valid >> (4 * h)) & cm;
+                    } else {
+                        const int lim = sidx[zs] - t0 - 32 * zt - 4 * h;                 // keep iff lr >= lim
+                        m = lim <= 0 ? ~0u : (lim >= 32 ? 0u : ~((1u << lim) - 1u));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int lr = (i & 3) + 8 * (i >> 2);
+                        s[zs][zt][i] = ((m >> lr) & 1u) ? s[zs][zt][i] : -INFINITY;
+                    }
+                }
+        };
+        // first streamed row of compute step u (dK/dV: a query index inside its head; dQ: a key index)
+        int c_s = 0;                                                        // step inside the head, of the step being exponentiated
+        auto step_t0 = [&]() -> int { return (u0 + c_s) * RT; };
+        auto step_needs_mask = [&](int t0, uint32_t valid) -> bool {
+            if constexpr (kDQ) return valid != ~0u || (p.causal && t0 + RT - 1 > s0w);
+            else return p.causal && t0 < s0w + SW - 1;
+        };
+
+        // ---- the stationary fragments and the first three steps have landed ------------------------------------------------------
+        if constexpr (KS == 8 && ZS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                         : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b1[0][4]), "+a"(b1[0][5]), "+a"(b1[0][6]), "+a"(b1[0][7]),
+                           "+a"(b1[1][0]), "+a"(b1[1][1]), "+a"(b1[1][2]), "+a"(b1[1][3]), "+a"(b1[1][4]), "+a"(b1[1][5]), "+a"(b1[1][6]), "+a"(b1[1][7])
+                         :: "memory");
+            asm volatile(""
+                         : "+a"(b2[0][0]), "+a"(b2[0][1]), "+a"(b2[0][2]), "+a"(b2[0][3]), "+a"(b2[0][4]), "+a"(b2[0][5]), "+a"(b2[0][6]), "+a"(b2[0][7]),
+                           "+a"(b2[1][0]), "+a"(b2[1][1]), "+a"(b2[1][2]), "+a"(b2[1][3]), "+a"(b2[1][4]), "+a"(b2[1][5]), "+a"(b2[1][6]), "+a"(b2[1][7])
+                         :: "memory");
+        } else if constexpr (KS == 8) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                         : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b1[0][4]), "+a"(b1[0][5]), "+a"(b1[0][6]), "+a"(b1[0][7]),
+                           "+a"(b2[0][0]), "+a"(b2[0][1]), "+a"(b2[0][2]), "+a"(b2[0][3]), "+a"(b2[0][4]), "+a"(b2[0][5]), "+a"(b2[0][6]), "+a"(b2[0][7])
+                         :: "memory");
+        } else {
+            static_assert(KS == 4 && ZS == 2, "");
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+                         : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b1[1][0]), "+a"(b1[1][1]), "+a"(b1[1][2]), "+a"(b1[1][3]),
+                           "+a"(b2[0][0]), "+a"(b2[0][1]), "+a"(b2[0][2]), "+a"(b2[0][3]), "+a"(b2[1][0]), "+a"(b2[1][1]), "+a"(b2[1][2]), "+a"(b2[1][3])
+                         :: "memory");
+        }
+
+        // ---- X(0): the score tiles of step 0 (plain order; once per workgroup) --------------------------------------------------
+        {
+            const uint32_t ra = opaque(sM + row_lane), ca = opaque(sM + rc_lane);
+#pragma unroll
+            for (int prod = 0; prod < 2; ++prod)
+#pragma unroll
+                for (int zt = 0; zt < ZT; ++zt) {
+                    if constexpr (!kDQ) {
+#pragma unroll
+                        for (int zs = 0; zs < ZS; ++zs) {
+                            (prod ? dA : sA)[zs][zt] = read_rc(opaque(ca), prod, zt);
+                            tile_ready((prod ? dA : sA)[zs][zt]);
+                        }
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const frag_t a = read_row(ra, (prod * ZT + zt) * KS + ks);
+#pragma unroll
+                        for (int zs = 0; zs < ZS; ++zs) {
+                            f32x16& d = (prod ? dA : sA)[zs][zt];
+                            const frag_t& bq = (prod ? b2 : b1)[zs][ks];
+                            if (kDQ && ks == 0) d = prod ? MM::qk_init(a, bq, ndl[zs]) : MM::qk_first(a, bq);
+                            else MM::qk_acc(d, a, bq);
+                        }
+                    }
+                }
+            static_assert(ZS * ZT == 2, "two score tiles per product");
+            if constexpr (ZS == 2) {
+                fence_mfma_result(sA[0][0], sA[1][0], dA[0][0], dA[1][0]);
+            } else {
+                fence_mfma_result(sA[0][0], sA[0][1], dA[0][0], dA[0][1]);
+            }
+        }
+        if constexpr (kGeneral && kDQ) vword_fetch(0);
+
+        // fragments 0 .. PF-1 of the first iteration's stream: columns of "step -1" (the copy of step 0 behind sY)
+        frag_t fr[RF];
+        {
+            const uint32_t ca0 = opaque(sY + col_lane);
+#pragma unroll
+            for (int f = 0; f < PF; ++f) fr[f] = read_col(ca0, f);
+        }
+
+        // ---- one iteration: Y(u-1) on the fragments `fp`, X(u+1) into (sn, dn), element-wise work of step u: (sc, dc) -> `fw` -----
+        using Plan = BwdW64Plan<E, KIND, kGeneral, LAG, PF>;
+        auto iteration = [&](int u, f32x16 (&sc)[ZS][ZT], f32x16 (&dc)[ZS][ZT], f32x16 (&sn)[ZS][ZT], f32x16 (&dn)[ZS][ZT],
+                             u32x4 (&fw)[NYP][ZS][2 * ZT], u32x4 (&fp)[NYP][ZS][2 * ZT]) {
+            constexpr Plan plan = Plan::make();
+            static_assert(plan.st_end[NSLOT - 1] == Plan::NSTEP, "every step placed");
+            static_assert(Plan::dma_slot(NPB - 1) < NSLOT, "the DMA batch fits behind the barrier");
+            // masked mode: the tile of step u is masked before it is exponentiated (rare: diagonal blocks, ragged / padded tiles)
+            if constexpr (kGeneral) {
+                const int t0 = step_t0();
+                uint32_t valid = ~0u;
+                if constexpr (kDQ) {
+                    valid = vword_take(u);
+                    vword_fetch(u + 1);
+                }
+                if (__builtin_expect(step_needs_mask(t0, valid), 0)) apply_mask(sc, t0, valid);
+            }
+            const uint32_t cimg = opaque(sY + col_lane);               // step u-1: columns
+            const uint32_t cimg2 = opaque(sM + col_lane);              // step u: the next iteration's first column fragments
+            const uint32_t rimg = opaque(sX + row_lane);               // step u+1: rows
+            const uint32_t rcimg = opaque(sX + rc_lane);               // step u+1: row constants
+            uint32_t dst = 0, soff = 0, srow = 0;                      // this iteration's DMA batch
+
+            // element n of step u: tile n / 16 = (zs, zt), accumulator register i = n % 16.
+            // part A: P = exp2(c S')   part B (LAG steps later): dS = P dP', and for an odd register the converts of its pair
+            auto el_step = [&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                if constexpr (n < 32) {
+                    constexpr int t = n >> 4, zs = ZS == 2 ? t : 0, zt = ZS == 2 ? 0 : t, i = n & 15;
+                    float x;
+                    if constexpr (kDQ) x = __builtin_fmaf(sc[zs][zt][i], c2, nl2[zs]);
+                    else x = sc[zs][zt][i] * c2;
+                    float e = fast_exp2(x);
+                    pin(e);
+                    sc[zs][zt][i] = e;
+                }
+                if constexpr (n >= LAG) {
+                    constexpr int m = n - LAG, t = m >> 4, zs = ZS == 2 ? t : 0, zt = ZS == 2 ? 0 : t, i = m & 15;
+                    float ds = sc[zs][zt][i] * dc[zs][zt][i];
+                    pin(ds);
+                    dc[zs][zt][i] = ds;
+                    if constexpr (i & 1) {
+                        typedef T t2 __attribute__((ext_vector_type(2)));
+                        constexpr int kk = 2 * zt + (i >> 3), w = (i & 7) >> 1;
+                        const f32x2 dsw = {dc[zs][zt][i - 1], dc[zs][zt][i]};
+                        uint32_t word = __builtin_bit_cast(uint32_t, __builtin_convertvector(dsw, t2));
+                        pin(word);
+                        fw[NYP - 1][zs][kk][w] = word;                 // dS: the last Y product (dK / dQ)
+                        if constexpr (!kDQ) {
+                            const f32x2 pw = {sc[zs][zt][i - 1], sc[zs][zt][i]};
+                            uint32_t word2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(pw, t2));
+                            pin(word2);
+                            fw[0][zs][kk][w] = word2;                  // P: dV
+                        }
+                    }
+                }
+            };
+            auto movable = [&](auto sc_) {
+                constexpr int sl = decltype(sc_)::value;
+                constexpr int n0 = sl ? plan.st_end[sl - 1] : 0, n1 = plan.st_end[sl];
+                static_for<n1 - n0>([&](auto dn_) { el_step(std::integral_constant<int, n0 + decltype(dn_)::value>{}); });
+            };
+            // fragment read PF ahead of stream position f (wraps into the next iteration's column fragments)
+            auto read_ahead = [&](auto fc) {
+                constexpr int g = decltype(fc)::value + PF;
+                if constexpr (g < NFY) fr[g % RF] = read_col(cimg, g);
+                else if constexpr (g < NF) fr[g % RF] = read_row(rimg, g - NFY);
+                else fr[g % RF] = read_col(cimg2, g - NF);
+            };
+
+            static_for<NSLOT>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int f = i / ZS, zs = i % ZS;
+                if constexpr (i == Plan::BAR_SLOT) {
+                    // every wave's pieces of step u+1 (issued two barriers ago) have landed; one batch (step u+2) stays in flight.
+                    // Behind the barrier every wave is done with the columns of step u-1: its slot takes step u+3.
+                    static_assert(NPB <= 15, "vmcnt literal");
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NPB) : "memory");
+                }
+                if constexpr (zs == 0) read_ahead(std::integral_constant<int, f>{});
+                if constexpr (i < NY) {
+                    constexpr int y = f / (2 * ZT * EB), kk = (f / EB) % (2 * ZT), eb = f % EB;
+                    MM::pv_acc(acc[y][zs][eb], fr[f % RF], __builtin_bit_cast(frag_t, fp[y][zs][kk]));
+                } else {
+                    constexpr int g = f - NFY, prod = g / (ZT * KS), zt = (g / KS) % ZT, ks = g % KS;
+                    f32x16& d = (prod ? dn : sn)[zs][zt];
+                    const frag_t& bq = (prod ? b2 : b1)[zs][ks];
+                    if constexpr (kDQ && ks == 0) d = prod ? MM::qk_init(fr[f % RF], bq, ndl[zs]) : MM::qk_first(fr[f % RF], bq);
+                    else MM::qk_acc(d, fr[f % RF], bq);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // dK/dV: the initial accumulators of the tiles whose first MFMA is RC_LEAD slots away (not before the barrier)
+                if constexpr (!kDQ) {
+                    constexpr int RC_LEAD = 2 * ZS + 1;
+                    static_for<2 * ZT>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value, prod = t / ZT, zt = t % ZT;
+                        constexpr int first = NY + ZS * (prod * ZT + zt) * KS;                 // slot of the tile's first MFMA (zs = 0)
+                        constexpr int at = first - RC_LEAD > Plan::BAR_SLOT ? first - RC_LEAD : Plan::BAR_SLOT;
+                        // one read per tile (a shared read would be copied with v_mov into the second tile)
+                        if constexpr (i == at) {
+#pragma unroll
+                            for (int z2 = 0; z2 < ZS; ++z2) (prod ? dn : sn)[z2][zt] = read_rc(opaque(rcimg), prod, zt);
+                        }
+                        // ... and the tiles are IN their registers one slot before the asm MFMA that takes them as its C operand:
+                        // whatever the compiler does to get them there (a v_mov behind the read) must not sit directly in front of
+                        // that MFMA -- VALU write -> MFMA operand needs wait states hipcc does not pad around asm (measured: the
+                        // tiles of the first key block wrong, those of the second, one MFMA later, right)
+                        if constexpr (i == first - 1) {
+#pragma unroll
+                            for (int z2 = 0; z2 < ZS; ++z2) pin((prod ? dn : sn)[z2][zt]);
+                        }
+                    });
+                }
+                if constexpr (i == Plan::BAR_SLOT + 1) {
+                    dst = sY;
+                    soff = d_off;
+                    srow = d_rc;
+                    advance_dma();
+                    asm volatile("" : "+s"(d_off));
+                }
+                static_for<NPB>([&](auto dc_) {
+                    constexpr int d = decltype(dc_)::value;
+                    if constexpr (i == Plan::dma_slot(d)) {
+                        if constexpr (d < NJ) dma_piece<d, d == 0>(rs1, voff[d < NJ ? d : 0], soff, dst);
+                        else if constexpr (d < 2 * NJ) dma_piece<d - NJ, d == NJ>(rs2, voff[d < 2 * NJ ? d - NJ : 0], soff, dst + IMG);
+                        else dma_dwords(rsc, rc_voff, srow, dst - wave_off + rc_dst_off);
+                    }
+                });
+                movable(std::integral_constant<int, i>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            rotate_slots();
+            if constexpr (kGeneral) {
+                if constexpr (kDQ) ++c_s;
+                else { if (++c_s == nps) c_s = 0; }
+            }
+        };
+
+        // a wave idles out its last MFMA before it leaves a copy of the loop body (see fa_fwd_w64.hpp: register-allocator copies of
+        // accumulator tiles on the exit edges)
+        auto leave_fence = []() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); };
+#if NNOP_BW64_STAMP
+        stamp[2] = __builtin_amdgcn_s_memtime();
+        stamp[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+        // iterations u = 0 .. n_steps (the last one runs Y(n_steps - 1) beside work on a copy of the last step that nobody uses)
+        int u = 0;
+        const int n_it = n_steps + 1;
+        if (n_it >= 2) {
+            for (;;) {
+                iteration(u, sA, dA, sB, dB, fA, fB);
+                iteration(u + 1, sB, dB, sA, dA, fB, fA);
+                u += 2;
+                if (u + 1 >= n_it) {
+                    leave_fence();
+                    break;
+                }
+            }
+        }
+        if (u < n_it) {
+            iteration(u, sA, dA, sB, dB, fA, fB);
+            leave_fence();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if NNOP_BW64_STAMP
+        stamp[4] = __builtin_amdgcn_s_memtime();
+        stamp[5] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+
+    // ---- epilogue: store the gradient rows of this wave's stationary rows ---------------------------------------------------------
+#pragma unroll
+    for (int zs = 0; zs < ZS; ++zs) {
+        const bool in = sidx[zs] < SL;
+        if constexpr (kDQ) {
+            T* row = (T*)p.dq + ((size_t)bh_s * p.QL + sidx_c[zs]) * E;
+            store_acc_row16<T, EB>(row, acc[0][zs], p.scale, h, in);
+        } else {
+            if constexpr (kGeneral) {
+                if (!svalid[zs]) {                           // padded-out key: its lane accumulated garbage (key on the lane)
+#pragma unroll
+                    for (int y = 0; y < NYP; ++y)
+#pragma unroll
+                        for (int eb = 0; eb < EB; ++eb) {
+                            fence_acc_result(acc[y][zs][eb]);
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) acc[y][zs][eb][i] = 0.f;
+                        }
+                }
+            }
+            const size_t ro = ((size_t)bh_s * p.KL + sidx_c[zs]) * E;
+            store_acc_row16<T, EB>((T*)p.dv + ro, acc[0][zs], 1.0f, h, in);
+            store_acc_row16<T, EB>((T*)p.dk + ro, acc[1][zs], p.scale, h, in);
+        }
+    }
+#if NNOP_BW64_STAMP
+    if (tid == 0) {
+        uint64_t* dbg = kDQ ? reinterpret_cast<uint64_t*>((T*)p.dq + ((size_t)bh_s * p.QL + s0w) * E)
+                            : reinterpret_cast<uint64_t*>((T*)p.dk + ((size_t)bh_s * p.KL + s0w) * E);
+        for (int i = 0; i < 6; ++i) dbg[i] = stamp[i];
+        dbg[6] = (uint64_t)n_steps;
+    }
+#endif
+}
+
+}  // namespace nnop

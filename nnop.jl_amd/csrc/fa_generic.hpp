@@ -113,8 +113,11 @@ __global__ __launch_bounds__(256) void fa_bwd_generic_pre_kernel(const BwdParams
     acc = wave_sum64(acc);
     if (lane == 0) {
         const float m = to_f32(((const T*)p.ms)[row]), l = to_f32(((const T*)p.ls)[row]);
-        p.nl[row] = (l > 0.f && m != -INFINITY) ? m + __logf(l) : -INFINITY;
-        p.delta[row] = acc;
+        // a row that sees no key: o = 0 / 0 = NaN there, so delta would be NaN and dS = P (dP - delta) = 0 * NaN would poison dq and
+        // dpair of the row and, through the shared key block, dK of live keys -- the tiled preprocess writes 0 as well (fa_bwd.hpp)
+        const bool live = l > 0.f && m != -INFINITY;
+        p.nl[row] = live ? m + __logf(l) : -INFINITY;
+        p.delta[row] = live ? acc : 0.f;
     }
 }
 

@@ -53,9 +53,10 @@ size_t norm_ws_bytes(const nnop_norm_desc& d, bool ln);
 inline bool emb_tiled(int e) { return e == 16 || e == 32 || e == 64 || e == 128; }
 inline bool emb_supported(int e) { return e >= 1 && e <= 512 && (e & (e - 1)) == 0; }
 
-// bytes of backward scratch: two fp32 per query row (folded log-sum-exp, delta), [2][B][QH][QL]
+// bytes of backward scratch: two fp32 per query row (folded log-sum-exp, delta), [2][B][QH][QLs], QLs = QL rounded up to 64
+// (the 64-row kernels copy whole steps of these rows; the padding holds neutral values)
 inline size_t bwd_workspace_bytes(const nnop_fa_desc& d) {
-    return 2 * (size_t)d.batch * d.qh * d.ql * sizeof(float);
+    return 2 * (size_t)d.batch * d.qh * (size_t)((d.ql + 63) & ~63) * sizeof(float);
 }
 // With a pair bias: the same + two head-major scratch matrices (a copy of the bias, dS), each
 // [B][QH][pad64(KL)][pad64(QL)] elements, 256-byte aligned (pair_tile.hpp).  0 when the staged path does not apply

@@ -13,7 +13,7 @@ extern "C" {
 struct nnop_fa_desc;
 
 /* Keys: the TuneKey enumerators of csrc/tuning.hpp (0 fwd_split, 1 fwd_nw, 2 fwd_w64, 3 bwd_big7,
- * 4 norm_bwd_cap, 5 bwd_nw, 6 fwd_exact_scale).  value -1 = automatic.  Returns the previous value, or INT_MIN for an
+ * 4 norm_bwd_cap, 5 bwd_nw, 6 fwd_exact_scale, 7 bwd_w64).  value -1 = automatic.  Returns the previous value, or INT_MIN for an
  * unknown key.  Process-wide; takes effect for launches issued after it returns. */
 int nnop_debug_set(int key, int value);
 

@@ -1,0 +1,142 @@
+"""GPU parity of the one-wave-per-SIMD backward (csrc/fa_bwd_w64.hpp: dK/dV and dQ as one kernel template with inline-asm MFMAs,
+LDS-DMA into dual-use images, a hand-placed three-stage pipeline) against the fp64 oracle's analytic gradients
+(src/attention_bwd.jl:86-156) -- forced through the debug hook so that small shapes reach it -- plus bitwise reproducibility
+across launches (the screen for races of the DMA ring and for reads of MFMA results that have not landed) and agreement with
+the 32-row kernels of csrc/fa_bwd.hpp on the same residuals."""
+import numpy as np
+import pytest
+import torch
+
+from util import make_inputs, oracle_bwd, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bwd(pkg, d, causal):
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], None, causal=causal, kpad_mask=d["mask"])
+    dq, dk, dv, dp = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], None, causal=causal, kpad_mask=d["mask"])
+    torch.cuda.synchronize()
+    assert dp is None
+    return dq, dk, dv
+
+
+def check(pkg, d, causal, dt, floor=False):
+    dq, dk, dv = run_bwd(pkg, d, causal)
+    rq, rk, rv, _ = oracle_bwd(d, causal)
+    assert_close("dv", dv, rv, dt, kind="grad", floor=floor)
+    assert_close("dk", dk, rk, dt, kind="grad", floor=floor)
+    assert_close("dq", dq, rq, dt, kind="grad", floor=floor)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("E", [64, 128])
+@pytest.mark.parametrize("which", [1, 2, 3])
+@pytest.mark.parametrize("QL,KL", [(256, 256), (64, 64), (255, 257), (512, 1024), (1100, 300), (33, 1000), (1, 1)])
+def test_noncausal(pkg, dev, tune, dt, E, which, QL, KL):
+    """which: 1 both passes on the new form, 2 dK/dV only, 3 dQ only (the other pass on csrc/fa_bwd.hpp)"""
+    if which != 1 and (QL, KL) not in ((255, 257), (512, 1024)):
+        pytest.skip("the mixed combinations on two shapes only")
+    tune(bwd_w64=which)
+    # a single key: dS = P (dP - delta) cancels to exactly zero in the oracle (tests/util.py, ABS_FLOOR)
+    check(pkg, make_inputs(91, 2, 2, 2, QL, KL, E, dt, dev), False, dt, floor=(KL == 1))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("E", [64, 128])
+@pytest.mark.parametrize("L", [64, 255, 256, 257, 700, 1024])
+@pytest.mark.parametrize("pad", [None, "ref"])
+def test_causal(pkg, dev, tune, dt, E, L, pad):
+    tune(bwd_w64=1)
+    check(pkg, make_inputs(92, 2, 2, 2, L, L, E, dt, dev, pad=pad), True, dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16"])
+@pytest.mark.parametrize("E", [64, 128])
+@pytest.mark.parametrize("QL,KL", [(300, 700), (700, 300)])
+def test_causal_rectangular(pkg, dev, tune, dt, E, QL, KL):
+    """top-left aligned causal mask for QL != KL (deviation 4)"""
+    tune(bwd_w64=1)
+    check(pkg, make_inputs(93, 2, 2, 2, QL, KL, E, dt, dev), True, dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("E", [64, 128])
+@pytest.mark.parametrize("pad", ["lens", "random", "ref"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_padmask(pkg, dev, tune, dt, E, pad, causal):
+    tune(bwd_w64=1)
+    check(pkg, make_inputs(94, 3, 2, 2, 700, 700, E, dt, dev, pad=pad), causal, dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("E", [64, 128])
+@pytest.mark.parametrize("QH,KH", [(4, 1), (6, 2), (8, 2)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_gqa(pkg, dev, tune, dt, E, QH, KH, causal):
+    """the dK/dV pass sweeps the q-heads of a kv head in one stream (ragged QL: every head's last step runs into the next head's
+    rows, which the padded row constants turn into P = 0)"""
+    tune(bwd_w64=1)
+    check(pkg, make_inputs(95, 2, QH, KH, 515, 515, E, dt, dev), causal, dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("E", [64, 128])
+def test_fully_masked_batch_and_dead_rows(pkg, dev, tune, dt, E):
+    """a batch without any valid key (dK = dV = 0 there, dQ = 0) and, under the causal mask with left padding, query rows that see
+    no key: zero dQ rows, finite dK / dV"""
+    tune(bwd_w64=1)
+    d = make_inputs(96, 3, 2, 2, 300, 300, E, dt, dev)
+    m = np.ones((3, 300), dtype=bool)
+    m[1, :] = False
+    m[2, :70] = False                    # left padding: causal queries 0..69 of batch 2 see nothing
+    d["mask"] = torch.tensor(m).to(dev)
+    for causal in (False, True):
+        dq, dk, dv = run_bwd(pkg, d, causal)
+        assert torch.isfinite(dk.float()).all() and torch.isfinite(dv.float()).all() and torch.isfinite(dq.float()).all()
+        assert float(dk[1].float().abs().max()) == 0.0 and float(dv[1].float().abs().max()) == 0.0
+        assert float(dq[1].float().abs().max()) == 0.0
+        if causal:
+            assert float(dq[2, :, :70].float().abs().max()) == 0.0
+        assert float(dk[2, :, :70].float().abs().max()) == 0.0
+        # the live part against the oracle (dead rows give NaN in the naive formula: compare batch 0 and the live rows of batch 2)
+        rq, rk, rv, _ = oracle_bwd({**d, "mask": d["mask"]}, causal)
+        assert_close("dk0", dk[0], rk[0], dt, kind="grad")
+        assert_close("dv0", dv[0], rv[0], dt, kind="grad")
+        assert_close("dq0", dq[0], rq[0], dt, kind="grad")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("E,causal,pad,QH,KH", [(64, False, None, 2, 2), (64, True, "ref", 4, 2), (128, False, None, 2, 2), (128, True, "lens", 4, 2)])
+def test_bitwise_reproducible_and_close_to_the_32_row_form(pkg, dev, tune, dt, E, causal, pad, QH, KH):
+    d = make_inputs(97, 2, QH, KH, 1100, 1100, E, dt, dev, pad=pad)
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], None, causal=causal, kpad_mask=d["mask"])
+    flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
+
+    def bwd():
+        g = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], None, causal=causal, kpad_mask=d["mask"])
+        torch.cuda.synchronize()
+        return g[:3]
+
+    tune(bwd_w64=1)
+    outs = []
+    for _ in range(4):
+        flush.fill_(1)
+        outs.append(bwd())
+    for other in outs[1:]:
+        for a, b, name in zip(outs[0], other, ("dq", "dk", "dv")):
+            assert torch.equal(a, b), name
+    tune(bwd_w64=0)
+    ref = bwd()
+    # same residuals, same products, another summation order and fp32 exponent arithmetic of another shape: equal to rounding
+    for a, b, name in zip(outs[0], ref, ("dq", "dk", "dv")):
+        scale = float(b.float().abs().max())
+        assert float((a.float() - b.float()).abs().max()) <= (1.6e-2 if dt == "bf16" else 2e-3) * scale, name
+
+
+@pytest.mark.parametrize("E", [64, 128])
+def test_long_sweep(pkg, dev, tune, E):
+    """many iterations of the ring (L = 4096: 128 / 64 steps per workgroup) and more workgroups than CUs"""
+    tune(bwd_w64=1)
+    d = make_inputs(98, 1, 4, 2, 4096, 4096, E, "bf16", dev)
+    check(pkg, d, False, "bf16")
+    check(pkg, d, True, "bf16")
