@@ -85,7 +85,7 @@ template <typename T, int E> static bool bwd_w64_ok(const nnop_fa_desc& d, int k
         if (kind == kBwdDKDV) {
             // one descriptor spans the q-heads of a kv head; the row constants of the whole launch behind another
             if ((long long)(d.qh / d.kh) * d.ql * rb >= (1LL << 32)) return false;
-            if (2LL * d.batch * d.qh * ((d.ql + 63) & ~63) * 4 >= (1LL << 32)) return false;
+            if ((long long)bwd_rows_padded(d) * 32 >= (1LL << 32)) return false;
             return true;
         }
         return (long long)d.kl * rb < (1LL << 32) && d.kl <= 64 * kMaxMaskTiles;
@@ -104,6 +104,9 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     if (n_rows > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.nl = (float*)a.workspace;
     p.delta = p.nl + n_rows;
+    // the fragment form of the row constants (fa_bwd_w64.hpp, dK/dV): behind the two vectors (n_rows is a multiple of 64: the offset
+    // keeps the workspace's alignment); 16-byte stores / LDS-DMA -> only with a 16-byte aligned workspace
+    p.rcf = (bwd_has_rcf(d) && ((uintptr_t)a.workspace & 15) == 0) ? (void*)(p.delta + n_rows) : nullptr;
     p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
     p.causal = d.causal ? 1 : 0;
     p.scale = (float)(1.0 / sqrt((double)E));
@@ -145,7 +148,7 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {
         const bool want_kv = w64_tune < 0 || w64_tune == 1 || w64_tune == 2;
         const bool want_q = w64_tune < 0 || w64_tune == 1 || w64_tune == 3;
-        w64_kv = want_kv && bwd_w64_ok<T, E>(d, kBwdDKDV);
+        w64_kv = want_kv && p.rcf != nullptr && bwd_w64_ok<T, E>(d, kBwdDKDV);
         w64_q = want_q && bwd_w64_ok<T, E>(d, kBwdDQ);
     }
     // 3. dK, dV
@@ -225,6 +228,7 @@ template <typename T> static int launch_bwd_generic(const nnop_fa_desc& d, const
     p.q = a.q; p.k = a.k; p.v = a.v; p.pair = a.pair; p.kpad = a.kpad;
     const long long n_rows = (long long)d.batch * d.qh * d.ql, n_krows = (long long)d.batch * d.kh * d.kl;
     p.QLs = d.ql;                                                          // dense rows here
+    p.rcf = nullptr;
     p.nl = (float*)a.workspace;
     p.delta = p.nl + n_rows;
     p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;

@@ -95,14 +95,18 @@ template <int E, int KIND> struct BwdW64Shape {
     static constexpr int KS = E / 16, EB = E / 32;
     static constexpr int RT = 32 * ZT, SW = 32 * ZS, RB = 2 * E;
     static constexpr int IMG = RT * RB;                       // one streamed tile image
-    static constexpr int RC = kDQ ? 0 : 512;                  // row constants of a step: nl[64], -delta[64] (fp32)
-    static constexpr int SLOT = 2 * IMG + RC, NS = 4;
+    // dK/dV: the row constants of a step travel as MFMA operand fragments (32 bytes per streamed row, see "row constants")
+    static constexpr int RCM = kDQ ? 0 : 1;                   // extra MFMA per score tile
+    static constexpr int RCB = kDQ ? 0 : RT * 32;
+    static constexpr int SLOT = 2 * IMG + RCB, NS = 4;
     static constexpr int NJ = IMG / 4096;                     // LDS-DMA pieces per wave, tile and tensor
-    static constexpr int NPB = 2 * NJ + (kDQ ? 0 : 1);        // DMA instructions per wave and step
+    static constexpr int NPB = 2 * NJ + RCM;                  // DMA instructions per wave and step
     static constexpr int NFY = NYP * 2 * ZT * EB, NFX = 2 * ZT * KS, NF = NFY + NFX;    // A-fragment stream of an iteration
-    static constexpr int NY = NFY * ZS, NX = NFX * ZS, NSLOT = NY + NX;               // MFMA slots
+    static constexpr int TB = ZS * (KS + RCM);                // X slots per (product, zt): [row-constant MFMA,] KS steps, each x ZS
+    static constexpr int NY = NFY * ZS, NX = 2 * ZT * TB, NSLOT = NY + NX;             // MFMA slots
     static constexpr int WG_ROWS = 4 * SW;
     static_assert(IMG % 4096 == 0 && NJ >= 1 && NJ <= 4, "four waves x NJ pieces = one image; 12-bit immediate");
+    static_assert(SLOT % 256 == 0, "XOR-addressed fragment reads: slot bases 256-byte aligned");
 };
 template <typename T, int E, int KIND> constexpr int fa_bwd_w64_lds_bytes(bool masked) {
     using SH = BwdW64Shape<E, KIND>;
@@ -110,65 +114,86 @@ template <typename T, int E, int KIND> constexpr int fa_bwd_w64_lds_bytes(bool m
 }
 
 // ---- the slot plan ------------------------------------------------------------------------------------------------------------
-// An iteration is NSLOT slots of one MFMA each: Y(u-1) first, then X(u+1).  Besides its MFMA a slot carries fixed work (fragment
-// read-ahead, row-constant reads, an LDS-DMA piece, the barrier) and a share of the element-wise stream of step u: step n issues
-// part A of element n (scale, v_exp_f32) and part B of element n - LAG (dS = P dP' and, for an odd element, the 16-bit converts
-// of the pair it closes).  No step depends on anything else in the iteration, so the stream is dealt out by issue cost alone:
-// the smallest per-slot budget for which a greedy in-order fill places everything (costs as in W64Plan).  Slot 0 takes no
-// movable work: it carries the iteration's bookkeeping, and the tiles written by the last MFMAs of the previous iteration are
-// not read before two MFMA slots have passed.
+// An iteration is NSLOT slots of one MFMA each: Y(u-1) first, then X(u+1).  The wave issues in order, so the time between two
+// MFMAs ("gap") is max(32, 8 + issue cost of what lies between them): the fixed work (what follows MFMA g: row-constant fragment
+// reads, LDS-DMA pieces and their address arithmetic; what precedes MFMA g+1: the barrier, the fragment read-ahead; behind the
+// last one the iteration's bookkeeping) plus a share of the element-wise stream of step u.  The stream is a list of small items
+// in a fixed order -- A(n): scale + v_exp_f32 of element n;  B(m), LAG elements behind: dS = P dP';  C(m) for odd m: the 16-bit
+// converts of the pair it closes -- and nothing in it depends on anything else in the iteration, so it is dealt out by cost alone:
+// the smallest per-gap budget for which a greedy in-order fill places everything (prices: tools/w64_gaps.py, calibrated on
+// tools/ubench/gapcost.hip).  One constraint: no B item in gap 0 -- the dP tiles are written by the last MFMAs of the previous
+// iteration, and a VALU read needs two MFMA slots of distance (tools/audit_w64.py checks the generated code).
 template <int E, int KIND, bool MASKED, int LAG, int PF> struct BwdW64Plan {
     using SH = BwdW64Shape<E, KIND>;
-    static constexpr int NSLOT = SH::NSLOT, NEL = 32, NSTEP = NEL + LAG;
+    static constexpr int NSLOT = SH::NSLOT, NEL = 32, NITEM = NEL + NEL + NEL / 2;
     static constexpr int BAR_SLOT = (SH::NFY - PF) * SH::ZS;  // the barrier opens this slot (all column reads of Y are issued)
-    static constexpr int FIRST = 1;                           // first slot with movable work
-    int st_end[NSLOT] = {};
+    int kind[NITEM] = {};                                     // 0 A, 1 B, 2 C
+    int el[NITEM] = {};
+    int it_end[NSLOT] = {};                                   // items [it_end[g-1], it_end[g]) go into gap g
     int cost[NSLOT] = {};
     int cap = 0;
 
+    // X slot j (relative to NY): tile tq = (product, zt), step st (0 = the row-constant MFMA when RCM), block zs
+    static constexpr bool x_is_rc(int j) { return SH::RCM && (j % SH::TB) / SH::ZS == 0; }
+    static constexpr int x_frag(int j) { return (j / SH::TB) * SH::KS + (j % SH::TB) / SH::ZS - SH::RCM; }        // row fragment index
+    static constexpr int rc_slot(int tq) { return SH::NY + tq * SH::TB; }                                       // its row-constant MFMA (zs = 0)
+    static constexpr int rc_read_slot(int tq) { return rc_slot(tq) - 3 > BAR_SLOT ? rc_slot(tq) - 3 : BAR_SLOT; }
     static constexpr int dma_slot(int d) { return BAR_SLOT + 1 + 2 * d; }          // piece d of the batch: one per second slot
-    static constexpr int fixed_cost(int s) {
+    // does slot s open with a fragment read-ahead, and of which stream position
+    static constexpr int slot_frag(int s) {                   // stream position whose first MFMA slot s is, or -1
+        if (s < SH::NY) return s % SH::ZS == 0 ? s / SH::ZS : -1;
+        const int j = s - SH::NY;
+        if (x_is_rc(j) || j % SH::ZS != 0) return -1;
+        return SH::NFY + x_frag(j);
+    }
+    static constexpr int pre_cost(int s) {                    // in front of MFMA s
         int c = 0;
-        if (s % SH::ZS == 0) c += 8;                          // fragment read-ahead (one ds_read_b128 or two transposed reads)
-        if (s == 0) c += 40;                                  // ring rotation, image bases, step counters, mask test
-        if (s == BAR_SLOT) c += 16;
-        if (s == BAR_SLOT + 1) c += 24;                       // scalar address arithmetic of the batch
-        for (int d = 0; d < SH::NPB; ++d)
-            if (s == dma_slot(d)) c += 24;
-        if (!SH::kDQ && s >= BAR_SLOT && s < SH::NY + SH::NX / 2 + SH::ZS * SH::KS) c += 4;   // row-constant reads (spread)
+        if (s == BAR_SLOT) c += 8;
+        const int f = slot_frag(s % NSLOT);
+        if (f >= 0) c += ((f + PF) % SH::NF < SH::NFY ? 24 : 16) + 2;              // two transposed reads / one ds_read_b128, xor, wait
+        if (s == NSLOT) c += 24 + 18 + 16 + (MASKED ? 30 : 0);                     // ring rotation, loop control, image bases, mask test
         return c;
     }
-    static constexpr int step_cost(int n) {
-        int c = n < NEL ? 12 : 0;
-        const int m = n - LAG;
-        if (m >= 0) c += 4 + ((m & 1) ? 4 * SH::NYP : 0);
+    static constexpr int post_cost(int s) {                   // behind MFMA s (before the movable share)
+        int c = 0;
+        for (int tq = 0; tq < 2 * SH::ZT * SH::RCM; ++tq)
+            if (s == rc_read_slot(tq)) c += 12;
+        if (s == BAR_SLOT + 1) c += SH::kDQ ? 24 : 60;
+        for (int d = 0; d < SH::NPB; ++d)
+            if (s == dma_slot(d)) c += 40 + ((d % SH::NJ == 0 || d >= 2 * SH::NJ) ? 14 : 0);
         return c;
+    }
+    static constexpr int item_cost(int k) { return k == 0 ? 12 : (k == 1 ? 4 : 4 * SH::NYP); }
+    constexpr void list() {
+        int n = 0;
+        for (int st = 0; st < NEL + LAG; ++st) {
+            if (st < NEL) { kind[n] = 0; el[n++] = st; }
+            const int m = st - LAG;
+            if (m >= 0) {
+                kind[n] = 1; el[n++] = m;
+                if (m & 1) { kind[n] = 2; el[n++] = m; }
+            }
+        }
     }
     constexpr bool fill(int budget) {
         int n = 0;
-        for (int sl = 0; sl < NSLOT; ++sl) {
-            int used = fixed_cost(sl);
-            if (sl >= FIRST)
-                while (n < NSTEP && used + step_cost(n) <= budget) used += step_cost(n++);
-            st_end[sl] = n;
-            cost[sl] = used;
+        for (int g = 0; g < NSLOT; ++g) {
+            int used = post_cost(g) + pre_cost(g + 1);
+            while (n < NITEM && used + item_cost(kind[n]) <= budget && !(g == 0 && kind[n] != 0)) used += item_cost(kind[n++]);
+            it_end[g] = n;
+            cost[g] = used;
         }
         cap = budget;
-        return n == NSTEP;
+        return n == NITEM;
     }
     static constexpr BwdW64Plan make() {
         BwdW64Plan pl{};
-        for (int b = 8; b <= 160; b += 2)
+        pl.list();
+        for (int b = 8; b <= 200; b += 2)
             if (pl.fill(b)) break;
         return pl;
     }
 };
-
-// LDS-DMA of 64 consecutive dwords (a step's row constants): lane l copies 4 bytes from base + soffset + 4 l to M0 + 4 l
-NNOP_DEV void dma_dwords(u32x4 rsrc, uint32_t voff, uint32_t soff, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
-}
 
 // 32 x E transposed accumulator tiles (rows = embedding in the registers, column = this lane's sequence row) -> one row of a
 // [rows][E] tensor, 16-byte stores (lane halves paired with v_permlane32_swap, as the forward's epilogue)
@@ -323,6 +348,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         }
     }
 
+    n_steps = __builtin_amdgcn_readfirstlane(n_steps);      // workgroup-uniform by construction; the LDS reads above made it a VGPR
     // ---- accumulators, stationary fragments (accumulator file) ---------------------------------------------------------------
     f32x16 acc[NYP][ZS][EB];
 #pragma unroll
@@ -350,40 +376,41 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         for (int j = 0; j < NJ; ++j) voff[j] = (uint32_t)(Img::src_of((wave * NJ + j) * 1024 + lane * 16) - j * 1024);
         const uint32_t wave_off = (uint32_t)(wave * NJ * 1024);
         const u32x4 rs1 = make_rsrc(t1p, t_bytes), rs2 = make_rsrc(t2p, t_bytes);
-        // row constants (dK/dV): nl / delta rows of the workspace, [B][QH][QLs] each (QLs = QL rounded up to 64: the padding holds
-        // nl = -inf, delta = 0, so a row past QL gives P = 0 whatever its Q / dO rows hold); even waves copy nl, odd waves delta
+        // row constants (dK/dV): 32 bytes per streamed row of the workspace (p.rcf, [B][QH][QLs] rows; the padding rows hold
+        // nl = -inf, delta = 0, so a row past QL gives P = 0 whatever its Q / dO rows hold), copied as they lie: 1 KiB = 32 rows per
+        // piece, wave w copies piece w mod (RT / 32) (the same bytes twice: every wave issues the same number of loads, which is
+        // what the counted vmcnt in front of the barrier needs)
         u32x4 rsc = rs1;
-        uint32_t rc_voff = 0, rc_dst_off = 0;
-        const uint32_t rc_head = (uint32_t)p.QLs * 4u;
+        uint32_t rc_voff = 0;
         if constexpr (!kDQ) {
-            const size_t rows_all = (size_t)p.B * p.QH * p.QLs;
-            rsc = make_rsrc(p.nl, (uint32_t)(2 * rows_all * 4));
-            rc_voff = (uint32_t)lane * 4u + ((wave & 1) ? (uint32_t)(rows_all * 4) : 0u);
-            rc_dst_off = 2 * IMG + ((wave & 1) ? 256u : 0u);
+            rsc = make_rsrc(p.rcf, (uint32_t)((size_t)p.B * p.QH * p.QLs * 32));
+            rc_voff = (uint32_t)lane * 16u + (uint32_t)((wave % (RT / 32)) * 1024);
         }
-        // running (head, step) of the NEXT step to copy, clamped to the last one (copied again into a slot nobody reads)
-        int d_it = 0, d_s = 0, d_g = 0;
+        const uint32_t rc_dst_off = (uint32_t)(2 * IMG) + (uint32_t)((wave % (RT / 32 > 0 ? RT / 32 : 1)) * 1024);
+        // running byte offsets of the NEXT step to copy (streamed tensors / row constants); dK/dV under GQA: the q-heads of the group
+        // one after the other, each from its step u0.  Branch-free (a branch would split the hand-placed loop body) and NOT clamped
+        // at the end of the stream: the copies past the last step are out of the descriptors' range (they read as zeros, or not
+        // at all) or fetch the next group's rows, into slots whose score tiles nobody uses.
+        int d_s = 0;
         uint32_t d_off = (uint32_t)u0 * (uint32_t)(RT * RB);
-        uint32_t d_rc = kDQ ? 0u : ((uint32_t)((b * p.QH + kvh * rep)) * rc_head + (uint32_t)(u0 * RT) * 4u);
-        const uint32_t rc_group = d_rc;
+        uint32_t d_rc = kDQ ? 0u : ((uint32_t)(b * p.QH + kvh * rep) * (uint32_t)p.QLs + (uint32_t)(u0 * RT)) * 32u;
+        const uint32_t jump_off = ((uint32_t)p.QL - (uint32_t)((nps - 1) * RT)) * (uint32_t)RB;      // last step of a head -> step u0 of the next
+        const uint32_t jump_rc = ((uint32_t)p.QLs - (uint32_t)((nps - 1) * RT)) * 32u;
         auto advance_dma = [&]() {
-            if (d_it + 1 < n_steps) {
-                ++d_it; ++d_s;
+            if constexpr (kDQ) {
                 d_off += (uint32_t)(RT * RB);
-                d_rc += (uint32_t)(RT * 4);
-                if constexpr (!kDQ) {
-                    if (d_s == nps) {
-                        d_s = 0; ++d_g;
-                        d_off = ((uint32_t)d_g * (uint32_t)p.QL + (uint32_t)(u0 * RT)) * (uint32_t)RB;
-                        d_rc = rc_group + (uint32_t)d_g * rc_head;
-                    }
-                }
+            } else {
+                const int s1 = d_s + 1;
+                const bool wrap = s1 == nps;
+                d_s = wrap ? 0 : s1;
+                d_off += wrap ? jump_off : (uint32_t)(RT * RB);
+                d_rc += wrap ? jump_rc : (uint32_t)(RT * 32);
             }
         };
         auto issue_step = [&](uint32_t slot) {          // slot: LDS byte address of the ring slot + this wave's share
             static_for<NJ>([&](auto jc) { constexpr int j = decltype(jc)::value; dma_piece<j, j == 0>(rs1, voff[j], d_off, slot); });
             static_for<NJ>([&](auto jc) { constexpr int j = decltype(jc)::value; dma_piece<j, j == 0>(rs2, voff[j], d_off, slot + IMG); });
-            if constexpr (!kDQ) dma_dwords(rsc, rc_voff, d_rc, slot - wave_off + rc_dst_off);
+            if constexpr (!kDQ) dma_piece<0, true>(rsc, rc_voff, d_rc, slot - wave_off + rc_dst_off);
         };
         // Ring slots as rotating scalars (each = slot address + wave_off):
         //   sY: step u-1 (column reads of phase Y; free behind the barrier -> target of the next batch), sM: step u,
@@ -423,6 +450,14 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             }
             if constexpr (ZS == 2) fence_valu_operand(ndl[0], ndl[1]);
         }
+        // dK/dV: B operand of the row-constant MFMAs: (1, 1, 1, 0 ...) in lane half 0 (it sums the three 16-bit terms of the fp32
+        // constant), zeros in lane half 1.  Opaque, and in the accumulator file like the other stationary operands.
+        frag_t bones;
+        if constexpr (!kDQ) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bones[j] = from_f32<T>((h == 0 && j < 3) ? 1.0f : 0.0f);
+            asm volatile("s_nop 1" : "+a"(bones));
+        }
 
         // score tiles: two sets (roles swap every iteration), P / dS fragments as words: two sets
         f32x16 sA[ZS][ZT], dA[ZS][ZT], sB[ZS][ZT], dB[ZS][ZT];
@@ -440,7 +475,11 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         typedef __attribute__((address_space(3))) const f32x4* lds_f4_p;
         const uint32_t row_lane = (uint32_t)Img::row_lane_base(lane) - wave_off;     // ring scalars include wave_off
         const uint32_t col_lane = (uint32_t)Img::col_lane_base(lane) - wave_off;
-        const uint32_t rc_lane = (uint32_t)(2 * IMG + 16 * h) - wave_off;
+        // row-constant fragments (dK/dV): streamed row 32 zt + r of the step, 32 bytes per row: [nl'] [-delta], each 8 elements of T
+        // (hi, mid, lo of the fp32 value, 0 ...).  Lane half 0 takes the product's chunk; lane half 1 meets zeros of the B operand,
+        // so it only has to read something finite: the delta chunk (nl may be -inf).
+        const uint32_t rc_lane0 = (uint32_t)(2 * IMG + r * 32 + 16 * h) - wave_off;      // S:  h = 0 -> nl chunk, h = 1 -> delta chunk
+        const uint32_t rc_lane1 = (uint32_t)(2 * IMG + r * 32 + 16) - wave_off;          // dP: delta chunk
         auto opaque = [](uint32_t x) { asm volatile("" : "+v"(x)); return x; };
         auto pin = [](auto& x) { asm volatile("" : "+v"(x)); };
         // row fragment g of phase X (g = (product * ZT + zt) * KS + ks) from the slot behind `ra` (= slot + row_lane)
@@ -458,18 +497,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             const s16x8 v8 = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
             return __builtin_bit_cast(frag_t, v8);
         };
-        // a tile written by compiler-visible code (LDS reads, possibly copies) -> C operand of an asm MFMA: 2 wait states
-        auto tile_ready = [](f32x16& t) { asm volatile("s_nop 1" : "+v"(t)); };
-        // dK/dV: initial accumulators of tile (product, zt): row constants of the step's rows 32 zt + acc_row(i, h)
-        auto read_rc = [&](uint32_t ca, int prod, int zt) -> f32x16 {
-            f32x16 t;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 v = *(lds_f4_p)(uintptr_t)(ca + (uint32_t)(prod * 256 + zt * 128 + g4 * 32));
-                t[4 * g4] = v[0]; t[4 * g4 + 1] = v[1]; t[4 * g4 + 2] = v[2]; t[4 * g4 + 3] = v[3];
-            }
-            return t;
-        };
+        // row constants of tile (product, zt) as an A fragment (see rc_lane0 / rc_lane1); rca = slot + rc_lane<product>
+        auto read_rcf = [&](uint32_t rca, int zt) -> frag_t { return *(lds_frag_p)(uintptr_t)(rca + (uint32_t)(zt * 1024)); };
 
         // ---- masks (masked mode): keep-bits of one score tile per lane, bit lr <-> accumulator register i, lr = acc_row(i, 0) ----
         // dK/dV (causal): register row = query t0 + 32 zt + lr + 4 h, lane = key: keep iff query >= key
@@ -535,17 +564,16 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
 
         // ---- X(0): the score tiles of step 0 (plain order; once per workgroup) --------------------------------------------------
         {
-            const uint32_t ra = opaque(sM + row_lane), ca = opaque(sM + rc_lane);
+            const uint32_t ra = opaque(sM + row_lane);
+            const uint32_t rca[2] = {opaque(sM + rc_lane0), opaque(sM + rc_lane1)};
 #pragma unroll
             for (int prod = 0; prod < 2; ++prod)
 #pragma unroll
                 for (int zt = 0; zt < ZT; ++zt) {
                     if constexpr (!kDQ) {
+                        const frag_t rc = read_rcf(rca[prod], zt);
 #pragma unroll
-                        for (int zs = 0; zs < ZS; ++zs) {
-                            (prod ? dA : sA)[zs][zt] = read_rc(opaque(ca), prod, zt);
-                            tile_ready((prod ? dA : sA)[zs][zt]);
-                        }
+                        for (int zs = 0; zs < ZS; ++zs) (prod ? dA : sA)[zs][zt] = MM::qk_first(rc, bones);
                     }
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
@@ -581,7 +609,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         auto iteration = [&](int u, f32x16 (&sc)[ZS][ZT], f32x16 (&dc)[ZS][ZT], f32x16 (&sn)[ZS][ZT], f32x16 (&dn)[ZS][ZT],
                              u32x4 (&fw)[NYP][ZS][2 * ZT], u32x4 (&fp)[NYP][ZS][2 * ZT]) {
             constexpr Plan plan = Plan::make();
-            static_assert(plan.st_end[NSLOT - 1] == Plan::NSTEP, "every step placed");
+            static_assert(plan.it_end[NSLOT - 1] == Plan::NITEM, "every item placed");
             static_assert(Plan::dma_slot(NPB - 1) < NSLOT, "the DMA batch fits behind the barrier");
             // masked mode: the tile of step u is masked before it is exponentiated (rare: diagonal blocks, ragged / padded tiles)
             if constexpr (kGeneral) {
@@ -596,47 +624,46 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             const uint32_t cimg = opaque(sY + col_lane);               // step u-1: columns
             const uint32_t cimg2 = opaque(sM + col_lane);              // step u: the next iteration's first column fragments
             const uint32_t rimg = opaque(sX + row_lane);               // step u+1: rows
-            const uint32_t rcimg = opaque(sX + rc_lane);               // step u+1: row constants
+            uint32_t rcimg[2] = {0, 0};                                // step u+1: row-constant fragments
+            if constexpr (!kDQ) { rcimg[0] = opaque(sX + rc_lane0); rcimg[1] = opaque(sX + rc_lane1); }
+            frag_t rcf[2 * ZT];
             uint32_t dst = 0, soff = 0, srow = 0;                      // this iteration's DMA batch
 
             // element n of step u: tile n / 16 = (zs, zt), accumulator register i = n % 16.
-            // part A: P = exp2(c S')   part B (LAG steps later): dS = P dP', and for an odd register the converts of its pair
-            auto el_step = [&](auto nc) {
-                constexpr int n = decltype(nc)::value;
-                if constexpr (n < 32) {
-                    constexpr int t = n >> 4, zs = ZS == 2 ? t : 0, zt = ZS == 2 ? 0 : t, i = n & 15;
+            // A: P = exp2(c S')    B: dS = P dP'    C (odd register): the 16-bit words of the pair it closes
+            auto item = [&](auto kc) {
+                constexpr int k = decltype(kc)::value, kind = plan.kind[k], n = plan.el[k];
+                constexpr int t = n >> 4, zs = ZS == 2 ? t : 0, zt = ZS == 2 ? 0 : t, i = n & 15;
+                if constexpr (kind == 0) {
                     float x;
                     if constexpr (kDQ) x = __builtin_fmaf(sc[zs][zt][i], c2, nl2[zs]);
                     else x = sc[zs][zt][i] * c2;
                     float e = fast_exp2(x);
                     pin(e);
                     sc[zs][zt][i] = e;
-                }
-                if constexpr (n >= LAG) {
-                    constexpr int m = n - LAG, t = m >> 4, zs = ZS == 2 ? t : 0, zt = ZS == 2 ? 0 : t, i = m & 15;
+                } else if constexpr (kind == 1) {
                     float ds = sc[zs][zt][i] * dc[zs][zt][i];
                     pin(ds);
                     dc[zs][zt][i] = ds;
-                    if constexpr (i & 1) {
-                        typedef T t2 __attribute__((ext_vector_type(2)));
-                        constexpr int kk = 2 * zt + (i >> 3), w = (i & 7) >> 1;
-                        const f32x2 dsw = {dc[zs][zt][i - 1], dc[zs][zt][i]};
-                        uint32_t word = __builtin_bit_cast(uint32_t, __builtin_convertvector(dsw, t2));
-                        pin(word);
-                        fw[NYP - 1][zs][kk][w] = word;                 // dS: the last Y product (dK / dQ)
-                        if constexpr (!kDQ) {
-                            const f32x2 pw = {sc[zs][zt][i - 1], sc[zs][zt][i]};
-                            uint32_t word2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(pw, t2));
-                            pin(word2);
-                            fw[0][zs][kk][w] = word2;                  // P: dV
-                        }
+                } else {
+                    typedef T t2 __attribute__((ext_vector_type(2)));
+                    constexpr int kk = 2 * zt + (i >> 3), w = (i & 7) >> 1;
+                    if constexpr (!kDQ) {                              // P first: its operands are the older ones
+                        const f32x2 pw = {sc[zs][zt][i - 1], sc[zs][zt][i]};
+                        uint32_t word2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(pw, t2));
+                        pin(word2);
+                        fw[0][zs][kk][w] = word2;                      // P: dV
                     }
+                    const f32x2 dsw = {dc[zs][zt][i - 1], dc[zs][zt][i]};
+                    uint32_t word = __builtin_bit_cast(uint32_t, __builtin_convertvector(dsw, t2));
+                    pin(word);
+                    fw[NYP - 1][zs][kk][w] = word;                     // dS: the last Y product (dK / dQ)
                 }
             };
             auto movable = [&](auto sc_) {
                 constexpr int sl = decltype(sc_)::value;
-                constexpr int n0 = sl ? plan.st_end[sl - 1] : 0, n1 = plan.st_end[sl];
-                static_for<n1 - n0>([&](auto dn_) { el_step(std::integral_constant<int, n0 + decltype(dn_)::value>{}); });
+                constexpr int k0 = sl ? plan.it_end[sl - 1] : 0, k1 = plan.it_end[sl];
+                static_for<k1 - k0>([&](auto dk_) { item(std::integral_constant<int, k0 + decltype(dk_)::value>{}); });
             };
             // fragment read PF ahead of stream position f (wraps into the next iteration's column fragments)
             auto read_ahead = [&](auto fc) {
@@ -648,45 +675,35 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
 
             static_for<NSLOT>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                constexpr int f = i / ZS, zs = i % ZS;
+                constexpr int f = Plan::slot_frag(i);                  // >= 0: this slot opens stream position f
                 if constexpr (i == Plan::BAR_SLOT) {
                     // every wave's pieces of step u+1 (issued two barriers ago) have landed; one batch (step u+2) stays in flight.
                     // Behind the barrier every wave is done with the columns of step u-1: its slot takes step u+3.
                     static_assert(NPB <= 15, "vmcnt literal");
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NPB) : "memory");
                 }
-                if constexpr (zs == 0) read_ahead(std::integral_constant<int, f>{});
+                if constexpr (f >= 0) read_ahead(std::integral_constant<int, f>{});
                 if constexpr (i < NY) {
-                    constexpr int y = f / (2 * ZT * EB), kk = (f / EB) % (2 * ZT), eb = f % EB;
-                    MM::pv_acc(acc[y][zs][eb], fr[f % RF], __builtin_bit_cast(frag_t, fp[y][zs][kk]));
+                    constexpr int fy = i / ZS, zs = i % ZS;
+                    constexpr int y = fy / (2 * ZT * EB), kk = (fy / EB) % (2 * ZT), eb = fy % EB;
+                    MM::pv_acc(acc[y][zs][eb], fr[fy % RF], __builtin_bit_cast(frag_t, fp[y][zs][kk]));
                 } else {
-                    constexpr int g = f - NFY, prod = g / (ZT * KS), zt = (g / KS) % ZT, ks = g % KS;
+                    constexpr int j = i - NY, tq = j / SH::TB, prod = tq / ZT, zt = tq % ZT, zs = (j % SH::TB) % ZS;
                     f32x16& d = (prod ? dn : sn)[zs][zt];
-                    const frag_t& bq = (prod ? b2 : b1)[zs][ks];
-                    if constexpr (kDQ && ks == 0) d = prod ? MM::qk_init(fr[f % RF], bq, ndl[zs]) : MM::qk_first(fr[f % RF], bq);
-                    else MM::qk_acc(d, fr[f % RF], bq);
+                    if constexpr (Plan::x_is_rc(j)) {
+                        d = MM::qk_first(rcf[tq], bones);              // the tile starts as its row constants
+                    } else {
+                        constexpr int g = Plan::x_frag(j), ks = g % KS;
+                        const frag_t& bq = (prod ? b2 : b1)[zs][ks];
+                        if constexpr (kDQ && ks == 0) d = prod ? MM::qk_init(fr[(NFY + g) % RF], bq, ndl[zs]) : MM::qk_first(fr[(NFY + g) % RF], bq);
+                        else MM::qk_acc(d, fr[(NFY + g) % RF], bq);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // dK/dV: the initial accumulators of the tiles whose first MFMA is RC_LEAD slots away (not before the barrier)
                 if constexpr (!kDQ) {
-                    constexpr int RC_LEAD = 2 * ZS + 1;
                     static_for<2 * ZT>([&](auto tc) {
-                        constexpr int t = decltype(tc)::value, prod = t / ZT, zt = t % ZT;
-                        constexpr int first = NY + ZS * (prod * ZT + zt) * KS;                 // slot of the tile's first MFMA (zs = 0)
-                        constexpr int at = first - RC_LEAD > Plan::BAR_SLOT ? first - RC_LEAD : Plan::BAR_SLOT;
-                        // one read per tile (a shared read would be copied with v_mov into the second tile)
-                        if constexpr (i == at) {
-#pragma unroll
-                            for (int z2 = 0; z2 < ZS; ++z2) (prod ? dn : sn)[z2][zt] = read_rc(opaque(rcimg), prod, zt);
-                        }
-                        // ... and the tiles are IN their registers one slot before the asm MFMA that takes them as its C operand:
-                        // whatever the compiler does to get them there (a v_mov behind the read) must not sit directly in front of
-                        // that MFMA -- VALU write -> MFMA operand needs wait states hipcc does not pad around asm (measured: the
-                        // tiles of the first key block wrong, those of the second, one MFMA later, right)
-                        if constexpr (i == first - 1) {
-#pragma unroll
-                            for (int z2 = 0; z2 < ZS; ++z2) pin((prod ? dn : sn)[z2][zt]);
-                        }
+                        constexpr int tq = decltype(tc)::value;
+                        if constexpr (i == Plan::rc_read_slot(tq)) rcf[tq] = read_rcf(rcimg[tq / ZT], tq % ZT);
                     });
                 }
                 if constexpr (i == Plan::BAR_SLOT + 1) {
@@ -701,7 +718,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                     if constexpr (i == Plan::dma_slot(d)) {
                         if constexpr (d < NJ) dma_piece<d, d == 0>(rs1, voff[d < NJ ? d : 0], soff, dst);
                         else if constexpr (d < 2 * NJ) dma_piece<d - NJ, d == NJ>(rs2, voff[d < 2 * NJ ? d - NJ : 0], soff, dst + IMG);
-                        else dma_dwords(rsc, rc_voff, srow, dst - wave_off + rc_dst_off);
+                        else dma_piece<0, true>(rsc, rc_voff, srow, dst - wave_off + rc_dst_off);
                     }
                 });
                 movable(std::integral_constant<int, i>{});

@@ -53,10 +53,13 @@ size_t norm_ws_bytes(const nnop_norm_desc& d, bool ln);
 inline bool emb_tiled(int e) { return e == 16 || e == 32 || e == 64 || e == 128; }
 inline bool emb_supported(int e) { return e >= 1 && e <= 512 && (e & (e - 1)) == 0; }
 
-// bytes of backward scratch: two fp32 per query row (folded log-sum-exp, delta), [2][B][QH][QLs], QLs = QL rounded up to 64
-// (the 64-row kernels copy whole steps of these rows; the padding holds neutral values)
+// bytes of backward scratch: two fp32 per query row (folded log-sum-exp, -delta), [2][B][QH][QLs], QLs = QL rounded up to 64
+// (the one-wave-per-SIMD kernels copy whole steps of these rows; the padding holds neutral values), and for the problems those
+// kernels take (16-bit, E = 64 / 128) the same two values once more as 2 x 8 elements of T per row (operand fragments)
+inline size_t bwd_rows_padded(const nnop_fa_desc& d) { return (size_t)d.batch * d.qh * (size_t)((d.ql + 63) & ~63); }
+inline bool bwd_has_rcf(const nnop_fa_desc& d) { return d.dtype != NNOP_F32 && (d.emb == 64 || d.emb == 128); }
 inline size_t bwd_workspace_bytes(const nnop_fa_desc& d) {
-    return 2 * (size_t)d.batch * d.qh * (size_t)((d.ql + 63) & ~63) * sizeof(float);
+    return bwd_rows_padded(d) * (2 * sizeof(float) + (bwd_has_rcf(d) ? 32 : 0));
 }
 // With a pair bias: the same + two head-major scratch matrices (a copy of the bias, dS), each
 // [B][QH][pad64(KL)][pad64(QL)] elements, 256-byte aligned (pair_tile.hpp).  0 when the staged path does not apply

@@ -26,7 +26,7 @@ def cost(op, args):
     if op == "s_barrier": return COST["barrier"]
     if op.startswith("ds_read_b128"): return COST["ds128"]
     if op.startswith("ds_"): return COST["dstr"]
-    if op.startswith("global_load_lds"): return COST["dma"]
+    if op.startswith("global_load_lds") or (op.startswith("buffer_load") and "lds" in args[-1]): return COST["dma"]
     if op.startswith("s_"): return COST["salu"]
     return COST["valu"]
 
@@ -34,8 +34,9 @@ def cost(op, args):
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "Li0ELb1"
     extra = sys.argv[sys.argv.index("--flags") + 1].split() if "--flags" in sys.argv else []
-    text = compile_asm("fa_fwd_bf16.hip", extra)
-    for name, body, meta in kernels(text, "fa_fwd_w64_kernel"):
+    bwd = "--bwd" in sys.argv          # the backward kernels of fa_bwd_w64.hpp (filter e.g. Li64ELi0ELi0E: E = 64, dK/dV, plain)
+    text = compile_asm("fa_bwd_bf16.hip" if bwd else "fa_fwd_bf16.hip", extra)
+    for name, body, meta in kernels(text, "fa_bwd_w64_kernel" if bwd else "fa_fwd_w64_kernel"):
         if flt not in name: continue
         lines = [l.split(";")[0].strip() for l in body.split("\n")]
         lines = [l for l in lines if l and (not l.startswith(".") or l.endswith(":"))]
