@@ -413,20 +413,14 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             if constexpr (!kDQ) dma_piece<0, true>(rsc, rc_voff, d_rc, slot - wave_off + rc_dst_off);
         };
         // Ring slots as rotating scalars (each = slot address + wave_off):
-        //   sY: step u-1 (column reads of phase Y; free behind the barrier -> target of the next batch), sM: step u,
-        //   sX: step u+1 (row reads of phase X), sF: step u+2 (in flight)
-        uint32_t sM = lds0 + wave_off, sX = sM + SLOT, sF = sM + 2 * SLOT, sY = sM + 3 * SLOT;
-        auto rotate_slots = [&]() { const uint32_t y = sY; sY = sM; sM = sX; sX = sF; sF = y; };
+        //   sY: step u-1 (column reads of phase Y), sM: step u, sX: step u+1 (row reads of phase X), sF: step u+2 (in flight),
+        //   sD: where the batch issued behind this iteration's barrier goes (step u+3) = the slot of step u-1, which every wave has
+        //       finished reading by then.  In iteration 0 there is no step -1: phase Y runs on zero fragments and reads the columns
+        //       of step 0 (finite data; sY = sM), and the batch goes to the fourth slot.
+        uint32_t sM = lds0 + wave_off, sX = sM + SLOT, sF = sM + 2 * SLOT, sD = sM + 3 * SLOT, sY = sM;
+        auto rotate_slots = [&]() { sY = sM; sM = sX; sX = sF; sF = sD; sD = sY; };
 
-        // ---- prologue: steps 0 (also into the slot phase Y(-1) reads: finite data under zero fragments), 1, 2 in flight ---------
-        issue_step(sM);
-        issue_step(sY);
-        advance_dma();
-        issue_step(sX);
-        advance_dma();
-        issue_step(sF);
-        advance_dma();
-
+        // ---- prologue: the stationary fragments first (X(0) needs them and step 0), then steps 0, 1, 2 ------------------------------
         frag_t b1[ZS][KS], b2[ZS][KS];
 #pragma unroll
         for (int zs = 0; zs < ZS; ++zs)
@@ -435,6 +429,12 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                 b1[zs][ks] = load_q_frag<frag_t>(b1p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
                 b2[zs][ks] = load_q_frag<frag_t>(b2p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
             }
+        issue_step(sM);
+        advance_dma();
+        issue_step(sX);
+        advance_dma();
+        issue_step(sF);
+        advance_dma();
         // dQ: the query's row constants are per lane: nl2 = c2 * nl (exponent offset), -delta as the initial accumulator of dP
         float nl2[ZS];
         f32x16 ndl[ZS];
@@ -539,27 +539,28 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             else return p.causal && t0 < s0w + SW - 1;
         };
 
-        // ---- the stationary fragments and the first three steps have landed ------------------------------------------------------
+        // ---- the stationary fragments and step 0 have landed (every wave's pieces: barrier); steps 1 and 2 stay in flight -- the
+        // barrier of iteration 0 waits for step 1 with the same counted wait as every other iteration -----------------------------------
         if constexpr (KS == 8 && ZS == 2) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+            asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
                          : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b1[0][4]), "+a"(b1[0][5]), "+a"(b1[0][6]), "+a"(b1[0][7]),
                            "+a"(b1[1][0]), "+a"(b1[1][1]), "+a"(b1[1][2]), "+a"(b1[1][3]), "+a"(b1[1][4]), "+a"(b1[1][5]), "+a"(b1[1][6]), "+a"(b1[1][7])
-                         :: "memory");
+                         : [nfl] "n"(2 * NPB) : "memory");
             asm volatile(""
                          : "+a"(b2[0][0]), "+a"(b2[0][1]), "+a"(b2[0][2]), "+a"(b2[0][3]), "+a"(b2[0][4]), "+a"(b2[0][5]), "+a"(b2[0][6]), "+a"(b2[0][7]),
                            "+a"(b2[1][0]), "+a"(b2[1][1]), "+a"(b2[1][2]), "+a"(b2[1][3]), "+a"(b2[1][4]), "+a"(b2[1][5]), "+a"(b2[1][6]), "+a"(b2[1][7])
                          :: "memory");
         } else if constexpr (KS == 8) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+            asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
                          : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b1[0][4]), "+a"(b1[0][5]), "+a"(b1[0][6]), "+a"(b1[0][7]),
                            "+a"(b2[0][0]), "+a"(b2[0][1]), "+a"(b2[0][2]), "+a"(b2[0][3]), "+a"(b2[0][4]), "+a"(b2[0][5]), "+a"(b2[0][6]), "+a"(b2[0][7])
-                         :: "memory");
+                         : [nfl] "n"(2 * NPB) : "memory");
         } else {
             static_assert(KS == 4 && ZS == 2, "");
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier"
+            asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
                          : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b1[1][0]), "+a"(b1[1][1]), "+a"(b1[1][2]), "+a"(b1[1][3]),
                            "+a"(b2[0][0]), "+a"(b2[0][1]), "+a"(b2[0][2]), "+a"(b2[0][3]), "+a"(b2[1][0]), "+a"(b2[1][1]), "+a"(b2[1][2]), "+a"(b2[1][3])
-                         :: "memory");
+                         : [nfl] "n"(2 * NPB) : "memory");
         }
 
         // ---- X(0): the score tiles of step 0 (plain order; once per workgroup) --------------------------------------------------
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         }
         if constexpr (kGeneral && kDQ) vword_fetch(0);
 
-        // fragments 0 .. PF-1 of the first iteration's stream: columns of "step -1" (the copy of step 0 behind sY)
+        // fragments 0 .. PF-1 of the first iteration's stream: columns of "step -1" (= step 0 again, under zero fragments)
         frag_t fr[RF];
         {
             const uint32_t ca0 = opaque(sY + col_lane);
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                     });
                 }
                 if constexpr (i == Plan::BAR_SLOT + 1) {
-                    dst = sY;
+                    dst = sD;
                     soff = d_off;
                     srow = d_rc;
                     advance_dma();

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static audit of the generated code of the inline-asm MFMA kernels (fa_fwd_w64.hpp).
+"""Static audit of the generated code of the inline-asm MFMA kernels (fa_fwd_w64.hpp, fa_bwd_w64.hpp).
 
 hipcc treats an `asm` MFMA as an ordinary 1-cycle instruction: it pads no wait states behind it, and its register allocator is
 free to split the live range of an MFMA result and put a copy (v_accvgpr_mov / v_accvgpr_read / v_mov) directly behind the MFMA
@@ -14,7 +14,7 @@ places where O is read, a fence at the end of a wave's last iteration); this scr
      an MFMA destination within MIN_GAP instructions);
   4. M0 is touched only by the LDS-DMA statements.
 
-usage: audit_w64.py [--flags "..."]   exit code 1 on any violation.  Used by tests/test_w64_codegen.py.
+usage: audit_w64.py [--only fwd|bwd] [--flags "..."]   exit code 1 on any violation.  Used by tests/test_w64_codegen.py.
 """
 import os
 import re
@@ -171,10 +171,16 @@ def main():
     if "--flags" in sys.argv:
         extra = sys.argv[sys.argv.index("--flags") + 1].split()
     bad = 0
-    for src in ("fa_fwd_bf16.hip", "fa_fwd_f16.hip"):
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None       # "fwd" | "bwd"
+    jobs = []
+    if only in (None, "fwd"):
+        jobs += [("fa_fwd_bf16.hip", "fa_fwd_w64_kernel"), ("fa_fwd_f16.hip", "fa_fwd_w64_kernel")]
+    if only in (None, "bwd"):
+        jobs += [("fa_bwd_bf16.hip", "fa_bwd_w64_kernel"), ("fa_bwd_f16.hip", "fa_bwd_w64_kernel")]
+    for src, pat in jobs:
         text = compile_asm(src, extra)
         n = 0
-        for name, body, meta in kernels(text, "fa_fwd_w64_kernel"):
+        for name, body, meta in kernels(text, pat):
             n += 1
             errs = audit(name, body, meta)
             print(f"{src} {name}: {'OK' if not errs else str(len(errs)) + ' violation(s)'}")
@@ -182,7 +188,7 @@ def main():
                 print("    " + e)
             bad += len(errs)
         if n == 0:
-            print(f"{src}: no fa_fwd_w64_kernel instantiation found")
+            print(f"{src}: no {pat} instantiation found")
             bad += 1
     return 1 if bad else 0
 

@@ -134,6 +134,22 @@ def check(E, rows=64):
     return worst
 
 
+def col_conflicts_with(E, xor_fn, rows=64):
+    """extra LDS cycles of the transposed column read if the image used `xor_fn(row)` as its chunk swizzle instead (addresses from
+    the operand map directly: lane 4q+p of a 16-lane group asks for row 16 kk + 8 s + 4 h + q, columns 32 eb + 16 g1 + 4 p ..)"""
+    worst = 0
+    for kk in range(rows // 16):
+        for eb in range(E // 32):
+            for s in range(2):
+                addrs = []
+                for l in range(64):
+                    h, g1, q, p = l >> 5, (l >> 4) & 1, (l >> 2) & 3, l & 3
+                    row, ch = 16 * kk + 8 * s + 4 * h + q, 4 * eb + 2 * g1 + (p >> 1)
+                    addrs.append(row * row_bytes(E) + ((ch ^ xor_fn(row)) << 4) + 8 * (p & 1))
+                worst = max(worst, conflicts(addrs, 8, [list(range(32)), list(range(32, 64))]))
+    return worst
+
+
 if __name__ == "__main__":
     for E in (64, 128):
         print(E, check(E))
