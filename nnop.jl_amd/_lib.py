@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = (
 
 # Test-only hooks (csrc/nnop_debug.h): exported by the library, deliberately NOT in the public header.
 DEBUG_SYMBOLS = ("nnop_debug_set", "nnop_debug_dev_build", "nnop_debug_fwd_form")
-FWD_FORMS = {0: "fa_fwd_kernel", 1: "fa_fwd_split_kernel", 2: "fa_fwd_w64_kernel"}
+FWD_FORMS = {0: "fa_fwd_kernel", 1: "fa_fwd_split_kernel", 2: "fa_fwd_w64_kernel", 3: "fa_fwd_generic_kernel"}
 # keys of nnop_debug_set == enum TuneKey (csrc/tuning.hpp)
 TUNE_KEYS = {"fwd_split": 0, "fwd_nw": 1, "fwd_w64": 2, "bwd_big7": 3, "norm_bwd_cap": 4, "bwd_nw": 5,
              "fwd_exact_scale": 6, "bwd_w64": 7}
@@ -104,6 +104,14 @@ def load():
             f"{LIB_PATH} not found: build it with `make -C nnop.jl_amd/csrc -j8` "
             "(or __graft_entry__.build()).  There is no CPU or PyTorch fallback.")
     lib = C.CDLL(LIB_PATH)
+    # the version first: a stale library may lack symbols this binding declares below (a bare AttributeError otherwise)
+    if not hasattr(lib, "nnop_abi_version"):
+        raise NNopLibraryMissing(f"{LIB_PATH} exports no nnop_abi_version: rebuild with `make -C nnop.jl_amd/csrc -j8`")
+    lib.nnop_abi_version.restype = C.c_int
+    lib.nnop_abi_version.argtypes = []
+    if lib.nnop_abi_version() != ABI_VERSION:
+        raise NNopLibraryMissing(f"{LIB_PATH} has ABI version {lib.nnop_abi_version()}, this binding needs "
+                                 f"{ABI_VERSION}: rebuild with `make -C nnop.jl_amd/csrc -j8`")
     vp, u8p = C.c_void_p, C.c_void_p
     lib.nnop_fa_fwd.restype = C.c_int
     lib.nnop_fa_fwd.argtypes = [C.POINTER(FaDesc), vp, vp, vp, vp, vp, vp, vp, u8p, vp]
@@ -135,17 +143,16 @@ def load():
     lib.nnop_shared_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.nnop_strerror.restype = C.c_char_p
     lib.nnop_strerror.argtypes = [C.c_int]
-    lib.nnop_abi_version.restype = C.c_int
-    lib.nnop_abi_version.argtypes = []
-    lib.nnop_debug_set.restype = C.c_int
-    lib.nnop_debug_set.argtypes = [C.c_int, C.c_int]
-    lib.nnop_debug_dev_build.restype = C.c_int
-    lib.nnop_debug_dev_build.argtypes = []
-    lib.nnop_debug_fwd_form.restype = C.c_int
-    lib.nnop_debug_fwd_form.argtypes = [C.POINTER(FaDesc), C.c_int, C.c_int]
-    if lib.nnop_abi_version() != ABI_VERSION:
-        raise NNopLibraryMissing(f"{LIB_PATH} has ABI version {lib.nnop_abi_version()}, this binding needs "
-                                 f"{ABI_VERSION}: rebuild with `make -C nnop.jl_amd/csrc -j8`")
+    # test-only hooks (csrc/nnop_debug.h): not part of the ABI, bound only when the library carries them
+    if hasattr(lib, "nnop_debug_set"):
+        lib.nnop_debug_set.restype = C.c_int
+        lib.nnop_debug_set.argtypes = [C.c_int, C.c_int]
+    if hasattr(lib, "nnop_debug_dev_build"):
+        lib.nnop_debug_dev_build.restype = C.c_int
+        lib.nnop_debug_dev_build.argtypes = []
+    if hasattr(lib, "nnop_debug_fwd_form"):
+        lib.nnop_debug_fwd_form.restype = C.c_int
+        lib.nnop_debug_fwd_form.argtypes = [C.POINTER(FaDesc), C.c_int, C.c_int]
     _lib = lib
     return lib
 

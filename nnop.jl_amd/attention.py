@@ -215,13 +215,21 @@ def grad_flash_attention(dO, o, ms, ls, q, k, v, pair=None, *, causal: bool, kpa
         dk = torch.empty_like(k)
         dv = torch.empty_like(v)
         dpair = torch.empty_like(pair) if pair is not None else None
-        nbytes = int(lib.nnop_fa_bwd_workspace_bytes(C.byref(d)))
+        nbytes = small = int(lib.nnop_fa_bwd_workspace_bytes(C.byref(d)))
         if nbytes != 0 and pair is not None:
-            nbytes = max(nbytes, int(lib.nnop_fa_bwd_workspace_bytes_pair(C.byref(d))))    # staged pair-bias path
+            # staged pair-bias path: two head-major bias-sized scratch matrices on top (the library returns the small size
+            # where that path does not exist: plain-HIP embedding dims, too many heads for its LDS block)
+            nbytes = max(nbytes, int(lib.nnop_fa_bwd_workspace_bytes_pair(C.byref(d))))
         if nbytes == 0:
             st = lib.nnop_fa_bwd(C.byref(d), *([C.c_void_p(0)] * 13), C.c_void_p(0), 0, C.c_void_p(0))
             _raise_status(st, q, k, v)
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        try:
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        except torch.cuda.OutOfMemoryError:
+            if nbytes == small:
+                raise
+            nbytes = small                     # no room for the scratch: the direct (element-wise) pair path needs none
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
         st = lib.nnop_fa_bwd(C.byref(d), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dpair), _ptr(dO), _ptr(o),
                              _ptr(ms), _ptr(ls), _ptr(q), _ptr(k), _ptr(v), _ptr(pair), _ptr(kpad_mask),
                              _ptr(ws), C.c_size_t(nbytes), _stream(q))

@@ -197,10 +197,11 @@ template <int E, int KIND, bool MASKED, int LAG, int PF> struct BwdW64Plan {
 
 // 32 x E transposed accumulator tiles (rows = embedding in the registers, column = this lane's sequence row) -> one row of a
 // [rows][E] tensor, 16-byte stores (lane halves paired with v_permlane32_swap, as the forward's epilogue)
+// (the caller has fenced the accumulators: one fence_acc_result in front of the epilogue)
 template <typename T, int EB> NNOP_DEV void store_acc_row16(T* rowp, f32x16 (&acc)[EB], float mul, int h, bool ok) {
 #pragma unroll
     for (int eb = 0; eb < EB; ++eb) {
-        fence_acc_result(acc[eb]);
+        acc_after_fence(acc[eb]);
         uint32_t pk[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
 
         // a wave idles out its last MFMA before it leaves a copy of the loop body (see fa_fwd_w64.hpp: register-allocator copies of
         // accumulator tiles on the exit edges)
-        auto leave_fence = []() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); };
+        auto leave_fence = []() { asm volatile(NNOP_FENCE_128 ::: "memory"); };
 #if NNOP_BW64_STAMP
         stamp[2] = __builtin_amdgcn_s_memtime();
         stamp[3] = __builtin_amdgcn_s_memrealtime();
@@ -765,6 +766,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
     }
 
     // ---- epilogue: store the gradient rows of this wave's stationary rows ---------------------------------------------------------
+    fence_acc_result(acc[0][0][0]);                         // the one fence of the epilogue (fa_fwd_w64.hpp, "RULE")
 #pragma unroll
     for (int zs = 0; zs < ZS; ++zs) {
         const bool in = sidx[zs] < SL;
@@ -778,7 +780,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                     for (int y = 0; y < NYP; ++y)
 #pragma unroll
                         for (int eb = 0; eb < EB; ++eb) {
-                            fence_acc_result(acc[y][zs][eb]);
+                            acc_after_fence(acc[y][zs][eb]);
 #pragma unroll
                             for (int i = 0; i < 16; ++i) acc[y][zs][eb][i] = 0.f;
                         }

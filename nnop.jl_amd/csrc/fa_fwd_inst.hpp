@@ -11,7 +11,6 @@
 #include "fa_fwd_w64.hpp"
 #include "fa_generic.hpp"
 #ifdef NNOP_DEV_BUILD
-#include "fa_fwd_split16.hpp"      // measured 7 % slower than the 32x32x16 body: experiments only (make DEV=1)
 #include <stdlib.h>
 #endif
 #include "fa_launch.hpp"
@@ -62,20 +61,13 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
-// split-KV form (fa_fwd_split.hpp / fa_fwd_split16.hpp): 16 waves per workgroup, plain mode, 16-bit types, E <= 64.
-// M16: the v_mfma_f32_16x16x32 body (E a multiple of 32), else the 32x32x16 body.
-template <typename T, int E, bool M16>
+// split-KV form (fa_fwd_split.hpp): 16 waves per workgroup, plain mode, 16-bit types, E <= 64.
+// (A v_mfma_f32_16x16x32 body of this form was built and measured 7 % slower in round 1 -- twice the MFMA issues on the port
+// that is the bottleneck; DESIGN.md section 5 -- and is no longer in the tree.)
+template <typename T, int E>
 static int launch_fwd_split(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
-#ifdef NNOP_DEV_BUILD
-    constexpr int lds = M16 ? fa_fwd_split16_lds_bytes<T, (M16 ? E : 32)>() : fa_fwd_split_lds_bytes<T, E>();
-    void (*kern)(const FwdParams);
-    if constexpr (M16) kern = fa_fwd_split16_kernel<T, E>;
-    else kern = fa_fwd_split_kernel<T, E>;
-#else
-    static_assert(!M16, "the 16x16x32 body is compiled under make DEV=1 only");
     constexpr int lds = fa_fwd_split_lds_bytes<T, E>();
     void (*kern)(const FwdParams) = fa_fwd_split_kernel<T, E>;
-#endif
     static_assert(lds <= 160 * 1024, "LDS budget");
     static unsigned long long lds_done = 0;
     if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
@@ -130,6 +122,8 @@ static inline int fwd_mode(const nnop_fa_desc& d, bool has_pair, bool has_mask) 
 static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
     const bool b16 = d.dtype != NNOP_F32;
     const int E = d.emb;
+    // the early exits of launch_fwd: embedding dims outside the tiled set (16-bit E = 256 runs the 32-row tiled kernel)
+    if (!(E == 256 && b16) && emb_generic(E)) return kFormGeneric;
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
     if (b16 && (E == 64 || E == 128)) {
         // 64-row waves (fa_fwd_w64.hpp): 4 waves x 64 rows, one wave per SIMD with the whole register file.  Measured
@@ -149,8 +143,7 @@ static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
     }
     if (b16 && E <= 64) {
         // plain mode: 16-wave split-KV workgroups (4 waves per SIMD); measured 5-13 % faster than the 8-wave form from 64 to
-        // 4096 workgroups.  Knob kTuneFwdSplit: 0 off, 1 / auto on; 16 (make DEV=1 builds only) the
-        // v_mfma_16x16x32 body of fa_fwd_split16.hpp -- correct, measured 7 % SLOWER.
+        // 4096 workgroups.  Knob kTuneFwdSplit: 0 off, 1 / auto on.
         if (mode == 0 && d.ql > 128 && d.kl >= 128 && tune_get(kTuneFwdSplit) != 0) return kFormSplit;
     }
     return kFormRow32;
@@ -174,14 +167,7 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
         }
     }
     if constexpr (sizeof(T) == 2 && E <= 64) {
-        if (form == kFormSplit) {
-#ifdef NNOP_DEV_BUILD
-            if constexpr (E % 32 == 0) {
-                if (tune_get(kTuneFwdSplit) == 16) return launch_fwd_split<T, E, true>(d, a, s);
-            }
-#endif
-            return launch_fwd_split<T, E, false>(d, a, s);
-        }
+        if (form == kFormSplit) return launch_fwd_split<T, E>(d, a, s);
     }
     int nw = 8, qb = 1;
     if (wg256 < 256 || d.ql <= 128) nw = 4;

@@ -48,7 +48,7 @@
 #ifndef NNOP_W64_STAMP
 #define NNOP_W64_STAMP 0
 #endif
-// E = 64 only: scale * log2(e) folded into Q (rounded to T once) and the exponent reference -m2 loaded as the INITIAL
+// E = 64 and E = 128: scale * log2(e) folded into Q (rounded to T once) and the exponent reference -m2 loaded as the INITIAL
 // accumulator of QK^T, so that a logit leaves the matrix pipe ready for v_exp_f32 (no v_fma per logit).  See the header.
 #ifndef NNOP_W64_PRESCALE
 #define NNOP_W64_PRESCALE 1
@@ -120,15 +120,20 @@ NNOP_MFMA_ASM(_Float16, f16x8, "v_mfma_f32_32x32x16_f16")
 #undef NNOP_MFMA_ASM
 
 // MFMA result -> first non-MFMA reader: the wait states hipcc does not insert after an asm MFMA.  The data dependence
-// through the operands keeps every reader below the statement.  64 idle cycles, not the table's 12 states: the last MFMA
-// may itself have been issued behind another one that still occupied the matrix pipe, and its final pass (accumulator
-// registers 12..15) then lands up to two MFMA times after its issue -- measured: with `s_nop 15; s_nop 3` the epilogue
-// read stale registers 13..15 of the last-written O tile in ~0.1 % of the rows, differently from run to run.  All three
-// sites (prologue score tile, rescale, epilogue) run once per workgroup or rarer.
+// through the operands keeps every reader below the statement.  Not the table's 12 states: the last MFMA may itself have been
+// issued behind another one that still occupied the matrix pipe, and its final pass (accumulator registers 12..15) then
+// lands up to two MFMA times = 64 cycles after its issue -- measured: with `s_nop 15; s_nop 3` (20 cycles) the epilogue read
+// stale registers 13..15 of the last-written O tile in ~0.1 % of the rows, differently from run to run; 64 cycles were clean.
+// RULE: a fence idles 128 cycles = 2 x the longest distance that reasoning allows (and > 6 x the distance measured unsafe).
+// All sites (prologue score tile, rescale, epilogue, leaving a copy of the loop body) run once per workgroup or rarer.  A run
+// of reads behind ONE fence needs the idle time once: the first statement is the fence, the others only carry the data
+// dependence (acc_after_fence) -- asm volatile statements keep their order.
+#define NNOP_FENCE_128 "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
 NNOP_DEV void fence_mfma_result(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    asm volatile(NNOP_FENCE_128 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
-NNOP_DEV void fence_acc_result(f32x16& a) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(a)); }
+NNOP_DEV void fence_acc_result(f32x16& a) { asm volatile(NNOP_FENCE_128 : "+a"(a)); }
+NNOP_DEV void acc_after_fence(f32x16& a) { asm volatile("" : "+a"(a)); }
 // VALU-written registers -> MFMA A/B operand inside an asm statement: 2 wait states
 template <typename F> NNOP_DEV void fence_valu_operand(F& a, F& b) { asm volatile("s_nop 1" : "+v"(a), "+v"(b)); }
 
@@ -577,7 +582,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             if (!first) {                                                 // first tile: O and l are still zero
 #pragma unroll
                 for (int eb = 0; eb < EB; ++eb) {
-                    fence_acc_result(oacc[z][eb]);
+                    if (z == 0 && eb == 0) fence_acc_result(oacc[z][eb]);
+                    else acc_after_fence(oacc[z][eb]);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) oacc[z][eb][i] *= alpha;
                     // back in the accumulator file BEFORE the paths merge: otherwise the merged value is allocated in
@@ -585,7 +591,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
                     asm volatile("" : "+a"(oacc[z][eb]));
                 }
                 if constexpr (kSum) {
-                    fence_acc_result(lacc[z]);
+                    acc_after_fence(lacc[z]);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) lacc[z][i] *= alpha;
                     asm volatile("" : "+a"(lacc[z]));
@@ -838,7 +844,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #ifdef NNOP_W64_NO_LEAVE_FENCE            // self-test of tools/audit_w64.py: it must flag the build without the fences
     auto leave_fence = []() {};
 #else
-    auto leave_fence = []() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); };
+    auto leave_fence = []() { asm volatile(NNOP_FENCE_128 ::: "memory"); };
 #endif
 #if NNOP_W64_STAMP
     stamp[2] = __builtin_amdgcn_s_memtime();
@@ -876,11 +882,12 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #endif
 
     // ---- epilogue: normalise, store o (16-byte stores: lane halves paired with v_permlane32_swap), ms, ls ------------
+    fence_acc_result(oacc[0][0]);                          // the one fence of the epilogue; every other read is acc_after_fence
 #pragma unroll
     for (int z = 0; z < 2; ++z) {
         float ltot;
         if constexpr (kSum) {
-            fence_acc_result(lacc[z]);
+            acc_after_fence(lacc[z]);
             ltot = lacc[z][0];                             // the MFMA already summed the keys of both lane halves
         } else {
             ltot = half_swap_sum(lp[z][0] + lp[z][1]);
@@ -889,7 +896,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         T* orow = (T*)p.o + ((size_t)bh * p.QL + (qi[z] < p.QL ? qi[z] : p.QL - 1)) * E;
 #pragma unroll
         for (int eb = 0; eb < EB; ++eb) {
-            fence_acc_result(oacc[z][eb]);
+            acc_after_fence(oacc[z][eb]);
             uint32_t pk[4][2];                             // [g][word]: this lane's 4 elements e = 32 eb + 8 g + 4 h + (0..3)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {

@@ -24,8 +24,9 @@ struct BwdArgs {
 
 // One per dtype (fa_fwd_{f32,f16,bf16}.hip).  Return an nnop_status.
 template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s);
-// Which kernel form launch_fwd picks (no launch): 0 = 32-row waves, 1 = split-KV, 2 = 64-row waves.
-enum FwdForm { kFormRow32 = 0, kFormSplit = 1, kFormW64 = 2 };
+// Which kernel form launch_fwd picks (no launch): 0 = 32-row waves, 1 = split-KV, 2 = 64-row waves, 3 = the plain-HIP kernel of
+// fa_generic.hpp (embedding dims outside the tiled set).
+enum FwdForm { kFormRow32 = 0, kFormSplit = 1, kFormW64 = 2, kFormGeneric = 3 };
 int fwd_form(const nnop_fa_desc& d, bool has_pair, bool has_mask);
 // One per dtype (fa_bwd_{f32,f16,bf16}.hip).
 template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s);
@@ -73,7 +74,10 @@ inline bool pair_staged_ok(const nnop_fa_desc& d) {
 }
 inline size_t bwd_workspace_bytes_pair(const nnop_fa_desc& d) {
     const size_t base = (bwd_workspace_bytes(d) + 255) & ~(size_t)255;
-    if (!pair_staged_ok(d)) return bwd_workspace_bytes(d);
+    // the staged path exists for the tiled MFMA kernels only (16 <= E <= 128, and 16-bit E = 256): other embedding dims run the
+    // plain-HIP kernels, which never touch the scratch
+    const bool tiled = emb_tiled(d.emb) || (d.emb == 256 && d.dtype != NNOP_F32);
+    if (!pair_staged_ok(d) || !tiled) return bwd_workspace_bytes(d);
     const size_t es = d.dtype == NNOP_F32 ? 4 : 2;
     const size_t one = (pair_scratch_elems(d) * es + 255) & ~(size_t)255;
     return base + 2 * one;

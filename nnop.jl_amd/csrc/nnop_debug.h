@@ -19,6 +19,7 @@ int nnop_debug_set(int key, int value);
 
 /* Which forward kernel form the launcher picks for this problem (reporting only: bench.py names the kernel its roofline line is
  * about): 0 = fa_fwd_kernel (32-row waves), 1 = fa_fwd_split_kernel (split-KV), 2 = fa_fwd_w64_kernel (64-row waves),
+ * 3 = fa_fwd_generic_kernel (plain HIP, embedding dims outside the tiled set),
  * negative = nnop_status of an invalid descriptor.  has_pair / has_mask: whether pair / kpad_mask would be non-NULL. */
 int nnop_debug_fwd_form(const struct nnop_fa_desc* d, int has_pair, int has_mask);
 

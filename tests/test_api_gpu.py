@@ -162,31 +162,6 @@ def test_split_kv_form_matches_plain_form_and_is_reproducible(pkg, dev, dt, E, Q
         assert rel < 1e-2
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("E,QL,KL,QH,KH", [(64, 1024, 1024, 2, 2), (64, 300, 192, 4, 2), (32, 515, 576, 2, 1), (64, 257, 4096, 2, 2)])
-def test_split_kv_16x16x32_body_matches_oracle(pkg, dev, dt, E, QL, KL, QH, KH, tune):
-    """The experimental v_mfma_f32_16x16x32 body of the split-KV forward (fa_fwd_split16.hpp, compiled under
-    `make DEV=1` only -- measured slower, not shipped): same contract, same oracle, bitwise reproducible; ragged
-    query counts, GQA, odd tile counts.  Skipped on the release library."""
-    if not pkg._lib.dev_build():
-        pytest.skip("fa_fwd_split16 is compiled into `make DEV=1` builds only")
-    d = make_inputs(44, 2, QH, KH, QL, KL, E, dt, dev, need_do=False)
-    tune(fwd_split=16, fwd_w64=0)
-    a = pkg._flash_attention(d["q"], d["k"], d["v"], causal=False)
-    b = pkg._flash_attention(d["q"], d["k"], d["v"], causal=False)
-    tune(fwd_split=1)
-    c = pkg._flash_attention(d["q"], d["k"], d["v"], causal=False)
-    torch.cuda.synchronize()
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
-    o_ref, ms_ref, ls_ref = oracle_fwd(d, False)
-    for res in (a, c):
-        assert_close("o", res[0], o_ref, dt)
-        assert_close("ms", res[1], ms_ref, dt)
-        lse = res[1].double().cpu().numpy() + np.log(res[2].double().cpu().numpy())
-        assert_close("lse", lse, ms_ref + np.log(ls_ref), dt)
-
-
 def test_hip_graph_capture_and_replay(pkg, dev):
     """The C ABI never allocates, synchronises or touches the default stream, so a forward + backward (and the row
     operators) capture into a HIP graph; replaying the graph on new data in the static buffers reproduces the eager

@@ -34,18 +34,21 @@ def test_audit_flags_the_build_without_leave_fences():
 def test_schedule_of_the_generated_loop_stays_balanced():
     """The slots of the hand-placed loop are dealt out by issue cost (W64Plan).  tools/w64_gaps.py prices the MFMA-to-MFMA gaps
     of the GENERATED code with the calibrated costs (profiles/r02/gapcost.log); a change that lets hipcc pile work into a few
-    gaps, or adds instructions to the loop, shows up as predicted cycles per MFMA (round 2: 43.1 at E = 64, 40.0 at E = 128;
-    the measured 46.2 / 42.5 track them)."""
+    gaps, or adds instructions to the loop, shows up as predicted cycles per MFMA (45.2 at E = 64, 42.1 at E = 128 with an LDS-DMA
+    piece priced at its calibrated 40 cycles -- round 2 priced it as a plain VALU instruction and printed 43.1 / 40.0; the measured
+    46.2 / 42.5 track the new numbers)."""
     import re
     gaps = os.path.join(ROOT, "tools", "w64_gaps.py")
     r = subprocess.run([sys.executable, gaps, "Li0ELb1"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     per = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"Li(\d+)ELi0ELb1\w*: .*? ([\d.]+) per MFMA", r.stdout)}
     assert set(per) == {64, 128}, r.stdout
-    assert per[64] <= 45.0 and per[128] <= 41.5, per
-    # the backward kernels (csrc/fa_bwd_w64.hpp; round 3, measured 49.8 / 50.6 / 44.8 / 38.2 cycles per algorithmic MFMA)
-    for flt, lim in (("Li64ELi0ELi0E", 45.0), ("Li64ELi1ELi0E", 49.5), ("Li128ELi0ELi0E", 46.0), ("Li128ELi1ELi0E", 39.5)):
-        r = subprocess.run([sys.executable, gaps, flt, "--bwd"], capture_output=True, text=True)
-        assert r.returncode == 0, r.stdout + r.stderr
-        m = re.search(r"([\d.]+) per MFMA", r.stdout)
-        assert m and float(m.group(1)) <= lim, r.stdout
+    assert per[64] <= 46.5 and per[128] <= 43.0, per
+    # the backward kernels (csrc/fa_bwd_w64.hpp; round 3, measured 49.8 / 50.6 / 44.8 / 38.2 cycles per algorithmic MFMA): one compile
+    r = subprocess.run([sys.executable, gaps, "IDF16b", "--bwd"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = {(int(m.group(1)), int(m.group(2))): float(m.group(3))
+           for m in re.finditer(r"Li(\d+)ELi(\d)ELi0E\w*: .*? ([\d.]+) per MFMA", r.stdout)}
+    lim = {(64, 0): 45.0, (64, 1): 49.5, (128, 0): 46.0, (128, 1): 39.5}        # (E, kind: 0 dK/dV, 1 dQ), plain mode
+    assert set(got) == set(lim), r.stdout
+    assert all(got[k] <= lim[k] for k in lim), got

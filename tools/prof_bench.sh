@@ -1,11 +1,11 @@
 #!/bin/bash
 # Evidence for one bench.py workload (default c2): rocprofv3 --kernel-trace --stats of the bench command, then SEPARATE --pmc
-# passes (never combined with trace domains): HBM bytes (FETCH_SIZE / WRITE_SIZE, gfx950 correction applied in the summary) and
+# passes (each with --kernel-trace for the per-dispatch rows, never with --sys-trace / hip / hsa trace domains): HBM bytes (FETCH_SIZE / WRITE_SIZE, gfx950 correction applied in the summary) and
 # the MFMA-busy ratio SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles).  Output: gpurun_out/prof_<cfg>/{kernel_stats.csv,
 # pmc_summary.json}; copy what should be judged into profiles/rNN/.
 # usage: tools/prof_bench.sh [config] [extra bench.py flags]
 cd "$(dirname "$0")/.."; export TMPDIR=/tmp
-CFG=${1:-c2}; shift
+CFG=${1:-c2}; shift || true
 OUT=gpurun_out/prof_$CFG; rm -rf $OUT; mkdir -p $OUT
 STEPS=100; [ "$CFG" != "c2" ] && STEPS=10
 BENCH="python3 bench.py --config $CFG --steps $STEPS --warmup 5 --no-cpu-baseline --no-bwd $*"

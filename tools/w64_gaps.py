@@ -54,7 +54,8 @@ def main():
         while i <= e:
             l = lines[i]
             m = re.match(r"s_cbranch\w* (\S+)", l)
-            rare = lambda blk: any("v_accvgpr_read" in x for x in blk) or sum("v_cndmask" in x for x in blk) >= 24     # rescale / mask blocks
+            rare = lambda blk: (any("v_accvgpr_read" in x for x in blk) or sum("v_cndmask" in x for x in blk) >= 24 or     # rescale / mask blocks
+                                sum(x.startswith("s_nop 15") for x in blk) >= 4)                                         # the exit fence
             if m and m.group(1) in labels and i < labels[m.group(1)] <= e and rare(lines[i:labels[m.group(1)]]):
                 i = labels[m.group(1)]
                 continue
