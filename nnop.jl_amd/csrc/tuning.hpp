@@ -19,7 +19,7 @@ enum TuneKey {
     kTuneBwdBig7,        // NNOP_BWD_BIG7    workgroups from which the 7-wave E=128 backward form is used
     kTuneNormBwdCap,     // NNOP_NORM_BWD_CAP partial rows of the norm pullbacks
     kTuneBwdNW,          // NNOP_BWD_NW      16-bit E <= 64 backward: waves per workgroup (4 | 8)
-    kTuneFwdExactScale,  // NNOP_FWD_EXACT_SCALE  1 = 64-row forward applies scale*log2e in fp32 per logit instead of folding it into Q
+    kTuneFwdExactScale,  // NNOP_FWD_EXACT_SCALE  64-row forward: 0 = fold scale*log2e into Q (rounded to T; opt-in, faster), 1 / auto = apply it in fp32 per logit
     kTuneBwdW64,         // NNOP_BWD_W64     one-wave-per-SIMD backward (fa_bwd_w64.hpp): 0 never, 1 both passes, 2 dK/dV only, 3 dQ only
     kTuneCount
 };

@@ -135,8 +135,9 @@ def test_bitwise_reproducible_and_close_to_the_32_row_form(pkg, dev, tune, dt, E
 
 @pytest.mark.parametrize("E", [64, 128])
 def test_long_sweep(pkg, dev, tune, E):
-    """many iterations of the ring (L = 4096: 128 / 64 steps per workgroup) and more workgroups than CUs"""
+    """many iterations of the ring (L = 3072: 96 / 48 steps per workgroup; the full-size launches of test_baseline_configs_gpu.py
+    go to 512 steps)"""
     tune(bwd_w64=1)
-    d = make_inputs(98, 1, 4, 2, 4096, 4096, E, "bf16", dev)
+    d = make_inputs(98, 1, 2, 1, 3072, 3072, E, "bf16", dev)
     check(pkg, d, False, "bf16")
     check(pkg, d, True, "bf16")

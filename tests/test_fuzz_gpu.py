@@ -64,6 +64,33 @@ def test_random_case(pkg, dev, case):
         assert_close("dpair", dp, rp, dt, sc, floor=True)
 
 
+def _cases_w64():
+    """second sweep for the kernels the benchmarks run: 16-bit, E in {64, 128}, lengths up to 1500 (several workgroups, many kv
+    tiles), no pair bias, the 64-row forward forced for half of the cases (the backward's one-wave-per-SIMD form is the default)"""
+    rng = np.random.default_rng(CASE_SEED + 7)
+    out = []
+    for i in range(28):
+        E = int(rng.choice([64, 128]))
+        dt = str(rng.choice(["bf16", "f16"]))
+        KH = int(rng.choice([1, 2]))
+        QH = KH * int(rng.choice([1, 2, 4]))
+        B = int(rng.integers(1, 3))
+        QL = int(rng.integers(1, 1500))
+        KL = int(rng.integers(1, 1500)) if rng.random() < 0.5 else QL
+        causal = bool(rng.random() < 0.5)
+        pad = [None, None, "lens", "random"][int(rng.integers(0, 4))]
+        w64 = int(rng.choice([-1, 1]))
+        out.append((i, dt, E, B, QH, KH, QL, KL, causal, pad, w64))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases_w64(), ids=lambda c: "{}-{}-E{}-B{}-H{}x{}-L{}x{}-c{}-{}-w{}".format(*c[:9], c[9] or "nopad", c[10]))
+def test_random_case_on_the_64_row_kernels(pkg, dev, tune, case):
+    i, dt, E, B, QH, KH, QL, KL, causal, pad, w64 = case
+    tune(fwd_w64=w64)
+    test_random_case(pkg, dev, (3000 + i, dt, E, B, QH, KH, QL, KL, causal, pad, False))
+
+
 def _row_cases():
     rng = np.random.default_rng(CASE_SEED + 1)
     out = []
