@@ -228,7 +228,7 @@ def main():
         ws = torch.empty(pkg.bwd_workspace_bytes(q, k, v, causal=causal), dtype=torch.uint8, device=dev)
         fb = lambda: (pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal, kpad_mask=kpad),
                       pkg.fa_bwd_into(dq, dk, dv, None, ws, do, o, ms, ls, q, k, v, causal=causal, kpad_mask=kpad))
-        nb = max(args.steps // 4, 5)
+        nb = max(args.steps // 4, 20)                    # >= 20 timed iterations whatever --steps says
         settle(fb)
         for _ in range(max(args.warmup // 4, 2)):
             fb()
@@ -246,9 +246,56 @@ def main():
         extra.update({
             "fwd_bwd_tflops": round(world * f_fwd * 3.5 / t_fb / 1e12, 2),
             "fwd_bwd_ms": round(t_fb * 1e3, 4),
-            "bwd_tflops": round(world * f_fwd * 2.5 / max(t_fb - kern_s, 1e-9) / 1e12, 2),
+            "fwd_bwd_iters": nb,
             "fwd_bwd_gbps": round(world * by_fb / t_fb / 1e9, 1),
         })
+        # ---- the backward alone, and its kernels one by one (rank 0's device; HIP events on the launch stream) -----------------
+        # nnop_fa_bwd = preprocess + dK/dV + dQ on one stream.  The per-kernel durations come from running prefixes of the three
+        # passes (test-only knob bwd_stages, csrc/tuning.hpp) and differencing: t(pre), t(pre + dK/dV) - t(pre), t(all) - t(pre + dK/dV).
+        bw = lambda: pkg.fa_bwd_into(dq, dk, dv, None, ws, do, o, ms, ls, q, k, v, causal=causal, kpad_mask=kpad)
+
+        def timed(fn, n):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(n):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            return ev0.elapsed_time(ev1) * 1e-3 / n
+
+        settle(bw)
+        t_all = timed(bw, nb)
+        stage_t = {}
+        for mask in (1, 3):
+            prev = pkg._lib.debug_set("bwd_stages", mask)
+            try:
+                stage_t[mask] = timed(bw, nb)
+            finally:
+                pkg._lib.debug_set("bwd_stages", prev)
+        bw()                                              # leave complete gradients behind
+        torch.cuda.synchronize()
+        bdesc = pkg._lib.FaDesc(dtype={"f32": 0, "f16": 1, "bf16": 2}[dtn], emb=E, ql=L, kl=L, qh=q.shape[1], kh=k.shape[1],
+                                batch=q.shape[0], causal=int(causal), emb_k=0, emb_v=0, kl_v=0, kh_v=0)
+        kn_kv, kn_q = pkg._lib.bwd_kernels(bdesc, False, kpad is not None)
+        f_bwd = 2.5 * f_fwd                               # algorithmic (S and dP counted once: SURVEY.md section 8(d))
+        t_pre, t_kv, t_q = stage_t[1], max(stage_t[3] - stage_t[1], 1e-9), max(t_all - stage_t[3], 1e-9)
+        extra["bwd_tflops"] = round(world * f_bwd / t_all / 1e12, 2)
+        extra["roofline_bwd"] = {
+            "bound": "mfma", "achieved": round(f_bwd / t_all / 1e12, 2), "peak": PEAK_TFLOPS[dtn], "unit": "TFLOP/s",
+            "frac": round(f_bwd / t_all / 1e12 / PEAK_TFLOPS[dtn], 4), "avg_call_us": round(t_all * 1e6, 2), "iters": nb,
+            "flops_per_call": int(f_bwd),
+            "kernels": [
+                {"name": "fa_bwd_pre_kernel", "avg_us": round(t_pre * 1e6, 2), "bound": "hbm"},
+                # products per pass: dK/dV = S, dP, dV, dK (2 of the 2.5 fwd-units); dQ = S, dP recomputed + dQ (0.5 algorithmic, 1.5 executed)
+                {"name": kn_kv, "avg_us": round(t_kv * 1e6, 2), "executed_tflops": round(2.0 * f_fwd / t_kv / 1e12, 1),
+                 "executed_frac": round(2.0 * f_fwd / t_kv / 1e12 / PEAK_TFLOPS[dtn], 4)},
+                {"name": kn_q, "avg_us": round(t_q * 1e6, 2), "executed_tflops": round(1.5 * f_fwd / t_q / 1e12, 1),
+                 "executed_frac": round(1.5 * f_fwd / t_q / 1e12 / PEAK_TFLOPS[dtn], 4)},
+            ],
+            "how": "HIP events around prefixes of the three passes (bwd_stages knob), differenced",
+        }
     if args.gather and dist is not None and (not rehearse or strong):
         # the one optional collective: replicate the unit-sharded O on every rank (RCCL all-gather over xGMI; gloo in rehearsal)
         if strong:

@@ -52,11 +52,11 @@ EXPORTED_SYMBOLS = (
 
 
 # Test-only hooks (csrc/nnop_debug.h): exported by the library, deliberately NOT in the public header.
-DEBUG_SYMBOLS = ("nnop_debug_set", "nnop_debug_dev_build", "nnop_debug_fwd_form")
+DEBUG_SYMBOLS = ("nnop_debug_set", "nnop_debug_dev_build", "nnop_debug_fwd_form", "nnop_debug_bwd_form")
 FWD_FORMS = {0: "fa_fwd_kernel", 1: "fa_fwd_split_kernel", 2: "fa_fwd_w64_kernel", 3: "fa_fwd_generic_kernel"}
 # keys of nnop_debug_set == enum TuneKey (csrc/tuning.hpp)
 TUNE_KEYS = {"fwd_split": 0, "fwd_nw": 1, "fwd_w64": 2, "bwd_big7": 3, "norm_bwd_cap": 4, "bwd_nw": 5,
-             "fwd_exact_scale": 6, "bwd_w64": 7}
+             "fwd_exact_scale": 6, "bwd_w64": 7, "bwd_stages": 8}
 
 
 class FaDesc(C.Structure):
@@ -150,9 +150,10 @@ def load():
     if hasattr(lib, "nnop_debug_dev_build"):
         lib.nnop_debug_dev_build.restype = C.c_int
         lib.nnop_debug_dev_build.argtypes = []
-    if hasattr(lib, "nnop_debug_fwd_form"):
-        lib.nnop_debug_fwd_form.restype = C.c_int
-        lib.nnop_debug_fwd_form.argtypes = [C.POINTER(FaDesc), C.c_int, C.c_int]
+    for name in ("nnop_debug_fwd_form", "nnop_debug_bwd_form"):
+        if hasattr(lib, name):
+            getattr(lib, name).restype = C.c_int
+            getattr(lib, name).argtypes = [C.POINTER(FaDesc), C.c_int, C.c_int]
     _lib = lib
     return lib
 
@@ -179,3 +180,11 @@ def fwd_form(desc: FaDesc, has_pair: bool = False, has_mask: bool = False) -> st
     if code < 0:
         raise ValueError(strerror(code))
     return FWD_FORMS[code]
+
+
+def bwd_kernels(desc: FaDesc, has_pair: bool = False, has_mask: bool = False):
+    """Names of the (dK/dV, dQ) kernels the launcher picks for this problem (reporting only; csrc/nnop_debug.h)."""
+    code = load().nnop_debug_bwd_form(C.byref(desc), int(has_pair), int(has_mask))
+    if code < 0:
+        raise ValueError(strerror(code))
+    return ("fa_bwd_w64_kernel<dK/dV>" if code & 1 else "fa_bwd_dkdv_kernel", "fa_bwd_w64_kernel<dQ>" if code & 2 else "fa_bwd_dq_kernel")

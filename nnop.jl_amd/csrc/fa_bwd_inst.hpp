@@ -77,19 +77,25 @@ static int launch_bwd_w64(const nnop_fa_desc& d, const BwdParams& p, hipStream_t
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds, s, pk);
     return NNOP_OK;
 }
-// Is the 64-row form instantiated for this problem, and do its 32-bit descriptor ranges hold it?
-template <typename T, int E> static bool bwd_w64_ok(const nnop_fa_desc& d, int kind) {
-    if constexpr (sizeof(T) != 2 || (E != 64 && E != 128)) return false;
-    else {
-        const long long rb = 2LL * E;
-        if (kind == kBwdDKDV) {
-            // one descriptor spans the q-heads of a kv head; the row constants of the whole launch behind another
-            if ((long long)(d.qh / d.kh) * d.ql * rb >= (1LL << 32)) return false;
-            if ((long long)bwd_rows_padded(d) * 32 >= (1LL << 32)) return false;
-            return true;
-        }
-        return (long long)d.kl * rb < (1LL << 32) && d.kl <= 64 * kMaxMaskTiles;
+// Is the one-wave-per-SIMD form instantiated for this problem (16-bit, E = 64 / 128, no pair bias), and do its 32-bit descriptor
+// ranges hold it?  A plain function of the descriptor: also behind nnop_debug_bwd_form (bench.py names the kernels it times).
+static inline bool bwd_w64_ok(const nnop_fa_desc& d, int kind) {
+    if (d.dtype == NNOP_F32 || (d.emb != 64 && d.emb != 128)) return false;
+    const long long rb = 2LL * d.emb;
+    if (kind == kBwdDKDV) {
+        // one descriptor spans the q-heads of a kv head; the row-constant fragments of the whole launch behind another
+        if ((long long)(d.qh / d.kh) * d.ql * rb >= (1LL << 32)) return false;
+        if ((long long)bwd_rows_padded(d) * 32 >= (1LL << 32)) return false;
+        return true;
     }
+    return (long long)d.kl * rb < (1LL << 32) && d.kl <= 64 * kMaxMaskTiles;
+}
+// bit 0: dK/dV runs fa_bwd_w64_kernel, bit 1: dQ does (knob kTuneBwdW64: 0 never, 1 both, 2 dK/dV only, 3 dQ only, auto = both)
+static inline int bwd_w64_forms(const nnop_fa_desc& d, bool has_pair, bool ws_aligned16) {
+    if (has_pair) return 0;
+    const int t = tune_get(kTuneBwdW64);
+    const bool want_kv = t < 0 || t == 1 || t == 2, want_q = t < 0 || t == 1 || t == 3;
+    return ((want_kv && ws_aligned16 && bwd_w64_ok(d, kBwdDKDV)) ? 1 : 0) | ((want_q && bwd_w64_ok(d, kBwdDQ)) ? 2 : 0);
 }
 
 template <typename T, int E, int MODE>
@@ -125,8 +131,10 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         hipLaunchKernelGGL((pair_pack_kernel<T>), dim3((unsigned)nblk), dim3(256), 1024 * d.qh * sizeof(T), s, pp);
     }
 
+    // measurement only (kTuneBwdStages, bench.py's per-kernel times): run a subset of the passes -- 1 preprocess, 2 dK/dV, 4 dQ
+    const int stages = tune_get(kTuneBwdStages) < 0 ? 7 : tune_get(kTuneBwdStages);
     // 1. preprocess
-    {
+    if (stages & 1) {
         const long long n_thr = n_rows * (E / 8);
         const long long grid = (n_thr + 255) / 256;
         if (grid > 0x7fffffffLL) return NNOP_ERR_SHAPE;
@@ -141,18 +149,11 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     // workgroups of the 7 / 8-wave E = 128 forms from which they are used: one per CU when every block has the same work,
     // two per CU under a causal mask (measured, tools/bwd_ab.py: 256 blocks non-causal +27 %, causal -9 %)
     const int big_thr = big_tune >= 0 ? big_tune : (d.causal ? 512 : 256);
-    // the one-wave-per-SIMD form (fa_bwd_w64.hpp): 16-bit, E = 64 / 128, plain / masked modes.  NNOP_BWD_W64: 0 never, 1 both
-    // passes wherever instantiated, 2 dK/dV only, 3 dQ only; automatic: wherever instantiated
-    const int w64_tune = tune_get(kTuneBwdW64);
-    bool w64_kv = false, w64_q = false;
-    if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {
-        const bool want_kv = w64_tune < 0 || w64_tune == 1 || w64_tune == 2;
-        const bool want_q = w64_tune < 0 || w64_tune == 1 || w64_tune == 3;
-        w64_kv = want_kv && p.rcf != nullptr && bwd_w64_ok<T, E>(d, kBwdDKDV);
-        w64_q = want_q && bwd_w64_ok<T, E>(d, kBwdDQ);
-    }
+    // the one-wave-per-SIMD form (fa_bwd_w64.hpp): 16-bit, E = 64 / 128, plain / masked modes
+    const int w64_forms = MODE <= 1 ? bwd_w64_forms(d, false, p.rcf != nullptr) : 0;
+    const bool w64_kv = (w64_forms & 1) != 0, w64_q = (w64_forms & 2) != 0;
     // 3. dK, dV
-    {
+    if (stages & 2) {
         int st = NNOP_OK;
         bool done = false;
         if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {
@@ -173,7 +174,7 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         if (st != NNOP_OK) return st;
     }
     // 4. dQ
-    {
+    if (stages & 4) {
         int st = NNOP_OK;
         bool done = false;
         if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {

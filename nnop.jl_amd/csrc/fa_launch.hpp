@@ -28,6 +28,8 @@ template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hi
 // fa_generic.hpp (embedding dims outside the tiled set).
 enum FwdForm { kFormRow32 = 0, kFormSplit = 1, kFormW64 = 2, kFormGeneric = 3 };
 int fwd_form(const nnop_fa_desc& d, bool has_pair, bool has_mask);
+// Which backward kernels launch_bwd picks (no launch): bit 0: dK/dV on fa_bwd_w64_kernel, bit 1: dQ on it (else fa_bwd.hpp's)
+int bwd_forms(const nnop_fa_desc& d, bool has_pair);
 // One per dtype (fa_bwd_{f32,f16,bf16}.hip).
 template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s);
 

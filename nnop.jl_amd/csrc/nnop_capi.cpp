@@ -19,7 +19,7 @@ static std::once_flag g_tune_once;
 static void tune_init() {
     static const char* const names[kTuneCount] = {"NNOP_FWD_SPLIT", "NNOP_FWD_NW",       "NNOP_FWD_W64",
                                                   "NNOP_BWD_BIG7",  "NNOP_NORM_BWD_CAP", "NNOP_BWD_NW",
-                                                  "NNOP_FWD_EXACT_SCALE", "NNOP_BWD_W64"};
+                                                  "NNOP_FWD_EXACT_SCALE", "NNOP_BWD_W64", "NNOP_BWD_STAGES"};
     for (int k = 0; k < kTuneCount; ++k) {
         const char* s = getenv(names[k]);
         __atomic_store_n(&g_tune[k], (s && *s) ? atoi(s) : -1, __ATOMIC_RELAXED);
@@ -71,6 +71,12 @@ int nnop_debug_fwd_form(const nnop_fa_desc* d, int has_pair, int has_mask) {
     const int st = check_desc(d);
     if (st != NNOP_OK) return st;
     return fwd_form(*d, has_pair != 0, has_mask != 0);
+}
+int nnop_debug_bwd_form(const nnop_fa_desc* d, int has_pair, int has_mask) {
+    const int st = check_desc(d);
+    if (st != NNOP_OK) return st;
+    (void)has_mask;
+    return bwd_forms(*d, has_pair != 0);
 }
 int nnop_debug_dev_build(void) {
 #ifdef NNOP_DEV_BUILD
