@@ -52,6 +52,8 @@ struct BwdParams {
     float* delta;    // [B][QH][QLs]  MINUS sum_e dO*o (the initial accumulator of dP); the plain-HIP kernels of fa_generic.hpp keep +delta here
     int   QL, KL, QH, KH, B, causal;
     int   QLs;       // row stride of nl / delta per (batch, q-head): QL rounded up to 64; the padding holds nl = -inf, delta = 0
+    int   fused;     // 1: no preprocess launch -- the dQ kernel of fa_bwd_w64.hpp computes the row constants of its own rows (and
+                     // writes `rcf` for the dK/dV kernel, which runs behind it)
     void* rcf;       // [B][QH][QLs][2][8] T, or null: nl and -delta once more, each as three 16-bit terms (hi, mid, lo, 0 ...) that sum to
                      // the fp32 value -- the form in which the dK/dV kernel of fa_bwd_w64.hpp feeds them to the matrix pipe
     int   n_blk;     // blocks along the workgroup's sequence axis
@@ -62,6 +64,24 @@ struct BwdParams {
     void* dpair_s;
     int   QLp, KLp;
 };
+
+// An fp32 row constant as three 16-bit terms (hi, mid, lo, 0 ...) whose sum is the value to ~24 bits: the form in which the dK/dV
+// kernel of fa_bwd_w64.hpp feeds it to the matrix pipe (one extra contraction step against (1, 1, 1, 0 ...)).  -inf -> (-inf, 0, 0).
+template <typename T> NNOP_DEV auto rc_split3(float x) {
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    t8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(0.f);
+    const T a = from_f32<T>(x);
+    o[0] = a;
+    const float r1 = x - to_f32(a);
+    if (r1 == r1 && r1 - r1 == 0.f) {                    // finite remainder
+        const T bb = from_f32<T>(r1);
+        o[1] = bb;
+        o[2] = from_f32<T>(r1 - to_f32(bb));
+    }
+    return o;
+}
 
 // -------------------------------------------------------------------------------------------------
 // Preprocess (replaces _flash_attention_bwd_preprocess!, src/attention_bwd.jl:163-197).
@@ -107,20 +127,7 @@ __global__ __launch_bounds__(256) void fa_bwd_pre_kernel(const BwdParams p, long
         if constexpr (sizeof(T) == 2) {
             if (p.rcf) {
                 typedef T t8 __attribute__((ext_vector_type(8)));
-                auto split3 = [](float x) -> t8 {
-                    t8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(0.f);
-                    const T a = from_f32<T>(x);
-                    o[0] = a;
-                    const float r1 = x - to_f32(a);
-                    if (r1 == r1 && r1 - r1 == 0.f) {                    // finite remainder (x = -inf: (-inf, 0, 0))
-                        const T bb = from_f32<T>(r1);
-                        o[1] = bb;
-                        o[2] = from_f32<T>(r1 - to_f32(bb));
-                    }
-                    return o;
-                };
+                auto split3 = [](float x) -> t8 { return rc_split3<T>(x); };
                 t8* dst = reinterpret_cast<t8*>(p.rcf) + 2 * prow;
                 dst[0] = split3(nl);
                 dst[1] = split3(-dl);

@@ -90,11 +90,12 @@ static inline bool bwd_w64_ok(const nnop_fa_desc& d, int kind) {
     }
     return (long long)d.kl * rb < (1LL << 32) && d.kl <= 64 * kMaxMaskTiles;
 }
-// bit 0: dK/dV runs fa_bwd_w64_kernel, bit 1: dQ does (knob kTuneBwdW64: 0 never, 1 both, 2 dK/dV only, 3 dQ only, auto = both)
+// bit 0: dK/dV runs fa_bwd_w64_kernel, bit 1: dQ does (knob kTuneBwdW64: 0 never, 1 both, 2 dK/dV only, 3 dQ only, 4 both with the
+// preprocess launch kept, auto = both)
 static inline int bwd_w64_forms(const nnop_fa_desc& d, bool has_pair, bool ws_aligned16) {
     if (has_pair) return 0;
     const int t = tune_get(kTuneBwdW64);
-    const bool want_kv = t < 0 || t == 1 || t == 2, want_q = t < 0 || t == 1 || t == 3;
+    const bool want_kv = t < 0 || t == 1 || t == 2 || t == 4, want_q = t < 0 || t == 1 || t == 3 || t == 4;
     return ((want_kv && ws_aligned16 && bwd_w64_ok(d, kBwdDKDV)) ? 1 : 0) | ((want_q && bwd_w64_ok(d, kBwdDQ)) ? 2 : 0);
 }
 
@@ -113,6 +114,7 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     // the fragment form of the row constants (fa_bwd_w64.hpp, dK/dV): behind the two vectors (n_rows is a multiple of 64: the offset
     // keeps the workspace's alignment); 16-byte stores / LDS-DMA -> only with a 16-byte aligned workspace
     p.rcf = (bwd_has_rcf(d) && ((uintptr_t)a.workspace & 15) == 0) ? (void*)(p.delta + n_rows) : nullptr;
+    p.fused = 0;
     p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
     p.causal = d.causal ? 1 : 0;
     p.scale = (float)(1.0 / sqrt((double)E));
@@ -133,8 +135,14 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
 
     // measurement only (kTuneBwdStages, bench.py's per-kernel times): run a subset of the passes -- 1 preprocess, 2 dK/dV, 4 dQ
     const int stages = tune_get(kTuneBwdStages) < 0 ? 7 : tune_get(kTuneBwdStages);
+    // the one-wave-per-SIMD form (fa_bwd_w64.hpp): 16-bit, E = 64 / 128, plain / masked modes
+    const int w64_forms = MODE <= 1 ? bwd_w64_forms(d, false, p.rcf != nullptr) : 0;
+    const bool w64_kv = (w64_forms & 1) != 0, w64_q = (w64_forms & 2) != 0;
+    // Both passes in that form: no preprocess launch -- the dQ kernel computes the row constants of its own rows and leaves them
+    // (fragment form) for the dK/dV kernel, which therefore runs BEHIND it.  (kTuneBwdW64 = 4: both passes, preprocess kept: A/B)
+    p.fused = (w64_kv && w64_q && tune_get(kTuneBwdW64) != 4) ? 1 : 0;
     // 1. preprocess
-    if (stages & 1) {
+    if ((stages & 1) && !p.fused) {
         const long long n_thr = n_rows * (E / 8);
         const long long grid = (n_thr + 255) / 256;
         if (grid > 0x7fffffffLL) return NNOP_ERR_SHAPE;
@@ -149,11 +157,8 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     // workgroups of the 7 / 8-wave E = 128 forms from which they are used: one per CU when every block has the same work,
     // two per CU under a causal mask (measured, tools/bwd_ab.py: 256 blocks non-causal +27 %, causal -9 %)
     const int big_thr = big_tune >= 0 ? big_tune : (d.causal ? 512 : 256);
-    // the one-wave-per-SIMD form (fa_bwd_w64.hpp): 16-bit, E = 64 / 128, plain / masked modes
-    const int w64_forms = MODE <= 1 ? bwd_w64_forms(d, false, p.rcf != nullptr) : 0;
-    const bool w64_kv = (w64_forms & 1) != 0, w64_q = (w64_forms & 2) != 0;
     // 3. dK, dV
-    if (stages & 2) {
+    auto run_dkdv = [&]() -> int {
         int st = NNOP_OK;
         bool done = false;
         if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {
@@ -171,10 +176,10 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
             if (MODE != 2 && (nw == 8 || nw == 81 || (nw < 0 && !d.causal && n8 >= 256))) { st = launch_dkdv<T, E, 8, C::BQ, MODE>(d, p, s); done = true; }
         }
         if (!done) st = launch_dkdv<T, E, C::NW_KV, C::BQ, MODE>(d, p, s);
-        if (st != NNOP_OK) return st;
-    }
+        return st;
+    };
     // 4. dQ
-    if (stages & 4) {
+    auto run_dq = [&]() -> int {
         int st = NNOP_OK;
         bool done = false;
         if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {
@@ -197,7 +202,14 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
             if (MODE != 2 && (nw == 8 || nw == 82 || (nw < 0 && !d.causal && n8 >= 256))) { st = launch_dq<T, E, 8, C::BK, MODE>(d, p, s); done = true; }
         }
         if (!done) st = launch_dq<T, E, C::NW_Q, C::BK, MODE>(d, p, s);
-        if (st != NNOP_OK) return st;
+        return st;
+    };
+    if (p.fused) {
+        if (stages & 4) { const int st = run_dq(); if (st != NNOP_OK) return st; }
+        if (stages & 2) { const int st = run_dkdv(); if (st != NNOP_OK) return st; }
+    } else {
+        if (stages & 2) { const int st = run_dkdv(); if (st != NNOP_OK) return st; }
+        if (stages & 4) { const int st = run_dq(); if (st != NNOP_OK) return st; }
     }
     if constexpr (MODE == 3) {
         const long long nblk = (long long)d.batch * (p.KLp / 32) * (p.QLp / 32);
@@ -229,7 +241,7 @@ template <typename T> static int launch_bwd_generic(const nnop_fa_desc& d, const
     p.q = a.q; p.k = a.k; p.v = a.v; p.pair = a.pair; p.kpad = a.kpad;
     const long long n_rows = (long long)d.batch * d.qh * d.ql, n_krows = (long long)d.batch * d.kh * d.kl;
     p.QLs = d.ql;                                                          // dense rows here
-    p.rcf = nullptr;
+    p.rcf = nullptr; p.fused = 0;
     p.nl = (float*)a.workspace;
     p.delta = p.nl + n_rows;
     p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;

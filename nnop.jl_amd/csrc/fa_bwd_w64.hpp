@@ -350,6 +350,50 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
     }
 
     n_steps = __builtin_amdgcn_readfirstlane(n_steps);      // workgroup-uniform by construction; the LDS reads above made it a VGPR
+
+    // ---- dQ: the row constants of this wave's queries: nl = -(ms log2e + log2 ls) / c2 (-inf: no visible key) and -delta ----------
+    // Either from the preprocess launch, or (p.fused: both passes run in this form) computed HERE, which saves that launch: the wave
+    // holds the rows anyway -- delta = sum_e dO o over the lane pair (l, l + 32) that shares a row -- and writes them in fragment
+    // form for the dK/dV kernel, which then runs BEHIND this one (src/attention_bwd.jl:163-197 is the reference's preprocess).
+    float rc_nl[ZS], rc_nd[ZS];
+    if constexpr (kDQ) {
+#pragma unroll
+        for (int zs = 0; zs < ZS; ++zs) {
+            const bool in = sidx[zs] < SL;
+            float nlv, ndv;
+            if (p.fused) {
+                const size_t row = (size_t)bh_s * p.QL + sidx_c[zs];
+                const T* orow = (const T*)p.o + row * E;
+                const T* drow = (const T*)p.d_o + row * E;
+                float part = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const frag_t a = *reinterpret_cast<const frag_t*>(drow + 16 * ks + 8 * h);
+                    const frag_t bq = *reinterpret_cast<const frag_t*>(orow + 16 * ks + 8 * h);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) part += to_f32(a[j]) * to_f32(bq[j]);
+                }
+                const float dl = half_swap_sum(part);
+                const float m = to_f32(((const T*)p.ms)[row]), l = to_f32(((const T*)p.ls)[row]);
+                nlv = -(m * kLog2e + __builtin_amdgcn_logf(l)) / c2;                    // v_log_f32 = log2
+                ndv = -dl;
+                if (!(l > 0.f) || !(nlv == nlv) || m == -INFINITY) { nlv = -INFINITY; ndv = 0.f; }
+                if (!in) { nlv = -INFINITY; ndv = 0.f; }
+                if (p.rcf && sidx[zs] < p.QLs && h == 0) {              // rows QL .. QLs-1: the neutral padding
+                    typedef T t8 __attribute__((ext_vector_type(8)));
+                    t8* dst = reinterpret_cast<t8*>(p.rcf) + 2 * ((size_t)bh_s * p.QLs + sidx[zs]);
+                    dst[0] = rc_split3<T>(nlv);
+                    dst[1] = rc_split3<T>(ndv);
+                }
+            } else {
+                const size_t ro = (size_t)bh_s * p.QLs + sidx_c[zs];
+                nlv = in ? p.nl[ro] : -INFINITY;
+                ndv = in ? p.delta[ro] : 0.f;                                            // the workspace holds -delta
+            }
+            rc_nl[zs] = nlv;
+            rc_nd[zs] = ndv;
+        }
+    }
     // ---- accumulators, stationary fragments (accumulator file) ---------------------------------------------------------------
     f32x16 acc[NYP][ZS][EB];
 #pragma unroll
@@ -442,12 +486,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         if constexpr (kDQ) {
 #pragma unroll
             for (int zs = 0; zs < ZS; ++zs) {
-                const size_t ro = (size_t)bh_s * p.QLs + sidx_c[zs];
-                const float nlv = p.nl[ro], dlv = p.delta[ro];
-                nl2[zs] = sidx[zs] < SL ? nlv * c2 : -INFINITY;            // nl = -inf (dead row) stays -inf: c2 > 0
-                const float nd = sidx[zs] < SL ? dlv : 0.f;                        // the workspace holds -delta
+                nl2[zs] = rc_nl[zs] * c2;                                  // nl = -inf (dead row / row past QL) stays -inf: c2 > 0
 #pragma unroll
-                for (int i = 0; i < 16; ++i) ndl[zs][i] = nd;
+                for (int i = 0; i < 16; ++i) ndl[zs][i] = rc_nd[zs];
             }
             if constexpr (ZS == 2) fence_valu_operand(ndl[0], ndl[1]);
         }

@@ -30,10 +30,11 @@ def check(pkg, d, causal, dt, floor=False):
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("E", [64, 128])
-@pytest.mark.parametrize("which", [1, 2, 3])
+@pytest.mark.parametrize("which", [1, 2, 3, 4])
 @pytest.mark.parametrize("QL,KL", [(256, 256), (64, 64), (255, 257), (512, 1024), (1100, 300), (33, 1000), (1, 1)])
 def test_noncausal(pkg, dev, tune, dt, E, which, QL, KL):
-    """which: 1 both passes on the new form, 2 dK/dV only, 3 dQ only (the other pass on csrc/fa_bwd.hpp)"""
+    """which: 1 both passes on the new form (the dQ kernel computes the row constants: no preprocess launch), 2 dK/dV only, 3 dQ only
+    (the other pass on csrc/fa_bwd.hpp), 4 both with the separate preprocess launch"""
     if which != 1 and (QL, KL) not in ((255, 257), (512, 1024)):
         pytest.skip("the mixed combinations on two shapes only")
     tune(bwd_w64=which)
