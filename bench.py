@@ -318,6 +318,28 @@ def main():
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         extra["allgather_o_ms"] = round(float(tg[0]) * 1e3, 4)
         extra["compute_plus_gather_tflops"] = round(n_rep * f_fwd / (t_wall / args.steps + float(tg[0])) / 1e12, 2)
+        if not strong and not rehearse and B >= 2:
+            # ... and overlapped: the batch in chunks, chunk i's gather (RCCL's stream) beside chunk i+1's forward (shard.py)
+            nch = 2 if B < 8 else 4
+            cuts = [B * i // nch for i in range(nch + 1)]
+            sl = [slice(cuts[i], cuts[i + 1]) for i in range(nch)]
+            o_ch = [o[c] for c in sl]
+            full_ch = [torch.empty((world,) + tuple(oc.shape), dtype=o.dtype, device=dev) for oc in o_ch]
+            kp_ch = [None if kpad is None else kpad[c] for c in sl]
+            step_chunk = lambda i: pkg.fa_fwd_into(o_ch[i], ms[sl[i]], ls[sl[i]], q[sl[i]], k[sl[i]], v[sl[i]], causal=causal, kpad_mask=kp_ch[i])
+            ov = lambda: pkg.shard.forward_with_overlapped_gather(step_chunk, o_ch, full_ch)
+            for _ in range(2):
+                ov()
+            barrier()
+            to0 = time.perf_counter()
+            for _ in range(5):
+                ov()
+            torch.cuda.synchronize()
+            to = torch.tensor([(time.perf_counter() - to0) / 5], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(to, op=dist.ReduceOp.MAX)
+            extra["compute_overlapped_with_gather_ms"] = round(float(to[0]) * 1e3, 4)
+            extra["compute_overlapped_with_gather_tflops"] = round(n_rep * f_fwd / float(to[0]) / 1e12, 2)
+            extra["gather_chunks"] = nch
 
     if rank != 0:
         if dist is not None:

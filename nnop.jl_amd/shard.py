@@ -98,6 +98,22 @@ def all_gather_units(local: torch.Tensor, n_units: int, group=None) -> torch.Ten
     return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
 
 
+def forward_with_overlapped_gather(step_chunk, o_chunks, full_chunks, group=None):
+    """The optional replication of O overlapped with compute (last hard part): the per-GPU batch is cut into
+    chunks along the batch axis; chunk i's all-gather is issued asynchronously right behind its forward launch -- RCCL runs it on
+    its own stream, ordered behind the launch by an event -- while chunk i+1 computes on the launch stream.
+
+    step_chunk(i): launches the forward of chunk i on the current stream (writes o_chunks[i]);
+    full_chunks[i]: [world, *o_chunks[i].shape] destination.  Returns after every gather has completed on the current stream."""
+    import torch.distributed as dist
+    works = []
+    for i in range(len(o_chunks)):
+        step_chunk(i)
+        works.append(dist.all_gather_into_tensor(full_chunks[i], o_chunks[i], group=group, async_op=True))
+    for w in works:
+        w.wait()
+
+
 def flash_attention_sharded(q, k, v, pair=None, *, causal: bool, kpad_mask=None,
                             world: Optional[int] = None, rank: Optional[int] = None,
                             gather: bool = False, group=None,
