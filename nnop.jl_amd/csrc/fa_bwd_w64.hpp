@@ -782,8 +782,18 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         stamp[3] = __builtin_amdgcn_s_memrealtime();
 #endif
         // iterations u = 0 .. n_steps (the last one runs Y(n_steps - 1) beside work on a copy of the last step that nobody uses)
+        // dQ under the causal mask: a wave whose last query precedes the keys of the workgroup's later steps stops computing there
+        // (the waves of a 256-query block see 64 .. 256 more keys than its first query) and only keeps the workgroup's DMA / barrier
+        // schedule going: one barrier and one batch per remaining iteration, as every live iteration has.
+        int n_live = n_steps;
+        if constexpr (kDQ && kGeneral) {
+            if (p.causal) {
+                const int t_w = (s0w + SW - 1) / RT + 1;
+                if (t_w < n_live) n_live = t_w;
+            }
+        }
         int u = 0;
-        const int n_it = n_steps + 1;
+        const int n_it = n_live + 1;
         if (n_it >= 2) {
             for (;;) {
                 iteration(u, sA, dA, sB, dB, fA, fB);
@@ -798,6 +808,15 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         if (u < n_it) {
             iteration(u, sA, dA, sB, dB, fA, fB);
             leave_fence();
+            ++u;
+        }
+        if constexpr (kDQ && kGeneral) {
+            for (; u <= n_steps; ++u) {
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NPB) : "memory");
+                issue_step(sD);
+                advance_dma();
+                rotate_slots();
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if NNOP_BW64_STAMP
