@@ -74,13 +74,14 @@ static int launch_bwd_w64(const nnop_fa_desc& d, const BwdParams& p, hipStream_t
     const long long n_wg = (long long)pk.n_blk * hd * d.batch;
     if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     pk.n_wg = (int)n_wg;
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds, s, pk);
+    if (n_wg * SH::NSPLIT > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg * SH::NSPLIT)), dim3(256), lds, s, pk);      // E = 256 dK/dV: every block twice (column halves)
     return NNOP_OK;
 }
 // Is the one-wave-per-SIMD form instantiated for this problem (16-bit, E = 64 / 128, no pair bias), and do its 32-bit descriptor
 // ranges hold it?  A plain function of the descriptor: also behind nnop_debug_bwd_form (bench.py names the kernels it times).
 static inline bool bwd_w64_ok(const nnop_fa_desc& d, int kind) {
-    if (d.dtype == NNOP_F32 || (d.emb != 64 && d.emb != 128)) return false;
+    if (d.dtype == NNOP_F32 || (d.emb != 64 && d.emb != 128 && d.emb != 256)) return false;
     const long long rb = 2LL * d.emb;
     if (kind == kBwdDKDV) {
         // one descriptor spans the q-heads of a kv head; the row-constant fragments of the whole launch behind another
@@ -161,7 +162,7 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     auto run_dkdv = [&]() -> int {
         int st = NNOP_OK;
         bool done = false;
-        if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {
+        if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128 || E == 256)) {
             if (w64_kv) { st = launch_bwd_w64<T, E, kBwdDKDV, MODE>(d, p, s); done = true; }
         }
         if constexpr (C::kBig7) if (!done) {
@@ -182,7 +183,7 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
     auto run_dq = [&]() -> int {
         int st = NNOP_OK;
         bool done = false;
-        if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128)) {
+        if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128 || E == 256)) {
             // plain mode needs whole steps of keys; a ragged KL takes the masked kernel
             if (w64_q) {
                 if (MODE == 0 && (d.kl & 31) != 0) st = launch_bwd_w64<T, E, kBwdDQ, 1>(d, p, s);

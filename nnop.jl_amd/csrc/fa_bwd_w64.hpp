@@ -57,15 +57,15 @@ enum : int { kBwdDKDV = 0, kBwdDQ = 1 };
 //   row read    (ds_read_b128, four 16-lane groups of distinct rows mod 16): x(row) must be a bijection of row & 15;
 //   column read (ds_read_b64_tr_b16, per 32-lane half: 4 consecutive rows x 64 bytes): the four rows must land in four different
 //               64-byte bank groups -- which the row swizzles of RowImg (row & 15, (row >> 1) & 7) do not give (4-way conflict).
-// E = 128 (256-byte rows): x = ((row & 3) << 2) | ((row >> 2) & 3)      (the guide's layout (b))
+// E = 128 (256-byte rows): x = ((row & 3) << 2) | ((row >> 2) & 3)      (the guide's layout (b)); E = 256: the same on the low 4 chunk bits
 // E =  64 (128-byte rows, two rows per bank row): x = bit1 << 2 | bit3 << 1 | bit2 of row
 // tools/dual_image.py restates every formula below on the CPU and checks data mapping and bank conflicts (tests/test_dual_image.py).
 template <typename T, int E> struct DualImg {
-    static_assert(sizeof(T) == 2 && (E == 64 || E == 128), "16-bit element types, E = 64 or 128");
+    static_assert(sizeof(T) == 2 && (E == 64 || E == 128 || E == 256), "16-bit element types, E = 64, 128 or 256");
     static constexpr int kRowBytes = 2 * E;
     static constexpr int bytes(int rows) { return rows * kRowBytes; }
     NNOP_DEV static constexpr int xor_of(int row) {
-        if constexpr (E == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
+        if constexpr (E >= 128) return ((row & 3) << 2) | ((row >> 2) & 3);      // rows of 256 bytes and more: the low 4 chunk bits
         else return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1);
     }
     // LDS-DMA: source byte (inside the dense tile) of the 16 bytes that land at image byte `o` (the destination is lane-linear)
@@ -81,7 +81,7 @@ template <typename T, int E> struct DualImg {
     // column read, 16-row step kk, 32-column block eb, half s:  (col_lane_base ^ (eb << 6) ^ (s << 5)) + (16 kk + 8 s) * kRowBytes
     NNOP_DEV static int col_lane_base(int lane) {
         const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
-        const int qx = E == 128 ? q : (q >> 1);
+        const int qx = E >= 128 ? q : (q >> 1);
         return (4 * h + q) * kRowBytes + 16 * (4 * qx + ((2 * g1 + (p >> 1)) ^ h)) + 8 * (p & 1);
     }
 };
@@ -89,10 +89,15 @@ template <typename T, int E> struct DualImg {
 // ---- shapes -------------------------------------------------------------------------------------------------------------------
 template <int E, int KIND> struct BwdW64Shape {
     static constexpr bool kDQ = KIND == kBwdDQ;
-    static constexpr int ZS = (kDQ || E == 64) ? 2 : 1;       // stationary 32-row blocks per wave
-    static constexpr int ZT = 2 / ZS;                         // streamed 32-row blocks per step
+    // E = 256: one block each way (the accumulator file holds 128 accumulator + 128 fragment registers of ONE 32-row block), and the
+    // dK/dV pass runs as NSPLIT = 2 launches-in-one: each workgroup keeps full-E K / V fragments (S and dP contract over all of E)
+    // but only half of the dK^T / dV^T accumulators -- 6 product-units instead of 4, spill-free.
+    static constexpr int ZS = E == 256 ? 1 : ((kDQ || E == 64) ? 2 : 1);       // stationary 32-row blocks per wave
+    static constexpr int ZT = E == 256 ? 1 : 2 / ZS;                           // streamed 32-row blocks per step
+    static constexpr int NSPLIT = (!kDQ && E == 256) ? 2 : 1;
     static constexpr int NYP = kDQ ? 1 : 2;                   // Y products
-    static constexpr int KS = E / 16, EB = E / 32;
+    static constexpr int KS = E / 16, EB = E / 32, EBA = EB / NSPLIT;          // EBA: 32-column blocks a workgroup accumulates
+    static constexpr int NEL = 16 * ZS * ZT;                  // score elements per lane and step
     static constexpr int RT = 32 * ZT, SW = 32 * ZS, RB = 2 * E;
     static constexpr int IMG = RT * RB;                       // one streamed tile image
     // dK/dV: the row constants of a step travel as MFMA operand fragments (32 bytes per streamed row, see "row constants")
@@ -101,12 +106,12 @@ template <int E, int KIND> struct BwdW64Shape {
     static constexpr int SLOT = 2 * IMG + RCB, NS = 4;
     static constexpr int NJ = IMG / 4096;                     // LDS-DMA pieces per wave, tile and tensor
     static constexpr int NPB = 2 * NJ + RCM;                  // DMA instructions per wave and step
-    static constexpr int NFY = NYP * 2 * ZT * EB, NFX = 2 * ZT * KS, NF = NFY + NFX;    // A-fragment stream of an iteration
+    static constexpr int NFY = NYP * 2 * ZT * EBA, NFX = 2 * ZT * KS, NF = NFY + NFX;    // A-fragment stream of an iteration
     static constexpr int TB = ZS * (KS + RCM);                // X slots per (product, zt): [row-constant MFMA,] KS steps, each x ZS
     static constexpr int NY = NFY * ZS, NX = 2 * ZT * TB, NSLOT = NY + NX;             // MFMA slots
     static constexpr int WG_ROWS = 4 * SW;
     static_assert(IMG % 4096 == 0 && NJ >= 1 && NJ <= 4, "four waves x NJ pieces = one image; 12-bit immediate");
-    static_assert(SLOT % 256 == 0, "XOR-addressed fragment reads: slot bases 256-byte aligned");
+    static_assert(SLOT % (RB > 256 ? RB : 256) == 0, "XOR-addressed fragment reads: slot bases aligned to a row / 256 bytes");
 };
 template <typename T, int E, int KIND> constexpr int fa_bwd_w64_lds_bytes(bool masked) {
     using SH = BwdW64Shape<E, KIND>;
@@ -125,7 +130,7 @@ template <typename T, int E, int KIND> constexpr int fa_bwd_w64_lds_bytes(bool m
 // iteration, and a VALU read needs two MFMA slots of distance (tools/audit_w64.py checks the generated code).
 template <int E, int KIND, bool MASKED, int LAG, int PF> struct BwdW64Plan {
     using SH = BwdW64Shape<E, KIND>;
-    static constexpr int NSLOT = SH::NSLOT, NEL = 32, NITEM = NEL + NEL + NEL / 2;
+    static constexpr int NSLOT = SH::NSLOT, NEL = SH::NEL, NITEM = NEL + NEL + NEL / 2;
     static constexpr int BAR_SLOT = (SH::NFY - PF) * SH::ZS;  // the barrier opens this slot (all column reads of Y are issued)
     int kind[NITEM] = {};                                     // 0 A, 1 B, 2 C
     int el[NITEM] = {};
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
     using Img = DualImg<T, E>;
     using MM = MfmaAsm<T>;
     constexpr bool kDQ = SH::kDQ, kGeneral = MODE != 0;
-    constexpr int ZS = SH::ZS, ZT = SH::ZT, NYP = SH::NYP, KS = SH::KS, EB = SH::EB;
+    constexpr int ZS = SH::ZS, ZT = SH::ZT, NYP = SH::NYP, KS = SH::KS, EB = SH::EBA;       // EB: the blocks THIS workgroup accumulates
     constexpr int RT = SH::RT, SW = SH::SW, RB = SH::RB, IMG = SH::IMG, SLOT = SH::SLOT, NS = SH::NS, NJ = SH::NJ, NPB = SH::NPB;
     constexpr int NFY = SH::NFY, NF = SH::NF, NY = SH::NY, NX = SH::NX, NSLOT = SH::NSLOT;
     constexpr int PF = NNOP_BW64_PF, RF = 4, LAG = NNOP_BW64_LAG;
@@ -268,7 +273,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             if (t_c < nps) nps = t_c;
         }
     } else {
-        const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk);
+        // (E = 256: the grid holds every workgroup NSPLIT times; copy `esplit` accumulates the column blocks esplit * EB ..)
+        const int lin = xcd_remap_chunked((int)blockIdx.x % p.n_wg, p.n_wg, p.n_blk);
         const int blk = lin % p.n_blk;
         bh_s = lin / p.n_blk;
         b = bh_s / p.KH;
@@ -279,6 +285,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         if (kGeneral && p.causal) u0 = s0wg / RT < nst ? s0wg / RT : nst;   // queries in front of the block's first key see none of it
         nps = nst - u0;
     }
+    const int esplit = SH::NSPLIT > 1 ? (int)blockIdx.x / p.n_wg : 0;
     const int s0w = s0wg + wave * SW;
     int sidx[ZS], sidx_c[ZS];
 #pragma unroll
@@ -491,15 +498,20 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                 for (int i = 0; i < 16; ++i) ndl[zs][i] = rc_nd[zs];
             }
             if constexpr (ZS == 2) fence_valu_operand(ndl[0], ndl[1]);
+            else asm volatile("s_nop 1" : "+v"(ndl[0]));
         }
         // dK/dV: B operand of the row-constant MFMAs: (1, 1, 1, 0 ...) in lane half 0 (it sums the three 16-bit terms of the fp32
         // constant), zeros in lane half 1.  Opaque, and in the accumulator file like the other stationary operands.
+        // (E = 256: the accumulator file is full -- 128 accumulator + 128 fragment registers -- and it lives in the arch VGPRs)
+        constexpr bool kBonesV = E == 256;
         frag_t bones;
         if constexpr (!kDQ) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bones[j] = from_f32<T>((h == 0 && j < 3) ? 1.0f : 0.0f);
-            asm volatile("s_nop 1" : "+a"(bones));
+            if constexpr (kBonesV) asm volatile("s_nop 1" : "+v"(bones));
+            else asm volatile("s_nop 1" : "+a"(bones));
         }
+        auto rc_tile = [&](frag_t rc) -> f32x16 { if constexpr (kBonesV) return MM::qk_first_v(rc, bones); else return MM::qk_first(rc, bones); };
 
         // score tiles: two sets (roles swap every iteration), P / dS fragments as words: two sets
         f32x16 sA[ZS][ZT], dA[ZS][ZT], sB[ZS][ZT], dB[ZS][ZT];
@@ -514,9 +526,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         // ---- LDS reads from integer addresses -----------------------------------------------------------------------------------
         typedef __attribute__((address_space(3))) const frag_t* lds_frag_p;
         typedef __attribute__((address_space(3))) s16x4* lds_tr_p;
-        typedef __attribute__((address_space(3))) const f32x4* lds_f4_p;
         const uint32_t row_lane = (uint32_t)Img::row_lane_base(lane) - wave_off;     // ring scalars include wave_off
-        const uint32_t col_lane = (uint32_t)Img::col_lane_base(lane) - wave_off;
+        const uint32_t col_lane = (uint32_t)Img::col_lane_base(lane) + (uint32_t)(esplit * EB * 64) - wave_off;   // + this split's first column block
         // row-constant fragments (dK/dV): streamed row 32 zt + r of the step, 32 bytes per row: [nl'] [-delta], each 8 elements of T
         // (hi, mid, lo of the fp32 value, 0 ...).  Lane half 0 takes the product's chunk; lane half 1 meets zeros of the B operand,
         // so it only has to read something finite: the delta chunk (nl may be -inf).
@@ -583,7 +594,15 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
 
         // ---- the stationary fragments and step 0 have landed (every wave's pieces: barrier); steps 1 and 2 stay in flight -- the
         // barrier of iteration 0 waits for step 1 with the same counted wait as every other iteration -----------------------------------
-        if constexpr (KS == 8 && ZS == 2) {
+        if constexpr (KS == 16) {
+            static_assert(ZS == 1, "");
+            asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
+                         : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b1[0][4]), "+a"(b1[0][5]), "+a"(b1[0][6]), "+a"(b1[0][7])
+                         : [nfl] "n"(2 * NPB) : "memory");
+            asm volatile("" : "+a"(b1[0][8]), "+a"(b1[0][9]), "+a"(b1[0][10]), "+a"(b1[0][11]), "+a"(b1[0][12]), "+a"(b1[0][13]), "+a"(b1[0][14]), "+a"(b1[0][15]) :: "memory");
+            asm volatile("" : "+a"(b2[0][0]), "+a"(b2[0][1]), "+a"(b2[0][2]), "+a"(b2[0][3]), "+a"(b2[0][4]), "+a"(b2[0][5]), "+a"(b2[0][6]), "+a"(b2[0][7]) :: "memory");
+            asm volatile("" : "+a"(b2[0][8]), "+a"(b2[0][9]), "+a"(b2[0][10]), "+a"(b2[0][11]), "+a"(b2[0][12]), "+a"(b2[0][13]), "+a"(b2[0][14]), "+a"(b2[0][15]) :: "memory");
+        } else if constexpr (KS == 8 && ZS == 2) {
             asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
                          : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b1[0][4]), "+a"(b1[0][5]), "+a"(b1[0][6]), "+a"(b1[0][7]),
                            "+a"(b1[1][0]), "+a"(b1[1][1]), "+a"(b1[1][2]), "+a"(b1[1][3]), "+a"(b1[1][4]), "+a"(b1[1][5]), "+a"(b1[1][6]), "+a"(b1[1][7])
@@ -616,7 +635,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                     if constexpr (!kDQ) {
                         const frag_t rc = read_rcf(rca[prod], zt);
 #pragma unroll
-                        for (int zs = 0; zs < ZS; ++zs) (prod ? dA : sA)[zs][zt] = MM::qk_first(rc, bones);
+                        for (int zs = 0; zs < ZS; ++zs) (prod ? dA : sA)[zs][zt] = rc_tile(rc);
                     }
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
@@ -630,11 +649,12 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                         }
                     }
                 }
-            static_assert(ZS * ZT == 2, "two score tiles per product");
             if constexpr (ZS == 2) {
                 fence_mfma_result(sA[0][0], sA[1][0], dA[0][0], dA[1][0]);
-            } else {
+            } else if constexpr (ZT == 2) {
                 fence_mfma_result(sA[0][0], sA[0][1], dA[0][0], dA[0][1]);
+            } else {
+                asm volatile(NNOP_FENCE_128 : "+v"(sA[0][0]), "+v"(dA[0][0]));
             }
         }
         if constexpr (kGeneral && kDQ) vword_fetch(0);
@@ -734,7 +754,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                     constexpr int j = i - NY, tq = j / SH::TB, prod = tq / ZT, zt = tq % ZT, zs = (j % SH::TB) % ZS;
                     f32x16& d = (prod ? dn : sn)[zs][zt];
                     if constexpr (Plan::x_is_rc(j)) {
-                        d = MM::qk_first(rcf[tq], bones);              // the tile starts as its row constants
+                        d = rc_tile(rcf[tq]);                           // the tile starts as its row constants
                     } else {
                         constexpr int g = Plan::x_frag(j), ks = g % KS;
                         const frag_t& bq = (prod ? b2 : b1)[zs][ks];
@@ -831,7 +851,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
     for (int zs = 0; zs < ZS; ++zs) {
         const bool in = sidx[zs] < SL;
         if constexpr (kDQ) {
-            T* row = (T*)p.dq + ((size_t)bh_s * p.QL + sidx_c[zs]) * E;
+            T* row = (T*)p.dq + ((size_t)bh_s * p.QL + sidx_c[zs]) * E + esplit * EB * 32;
             store_acc_row16<T, EB>(row, acc[0][zs], p.scale, h, in);
         } else {
             if constexpr (kGeneral) {
@@ -846,7 +866,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                         }
                 }
             }
-            const size_t ro = ((size_t)bh_s * p.KL + sidx_c[zs]) * E;
+            const size_t ro = ((size_t)bh_s * p.KL + sidx_c[zs]) * E + esplit * EB * 32;
             store_acc_row16<T, EB>((T*)p.dv + ro, acc[0][zs], 1.0f, h, in);
             store_acc_row16<T, EB>((T*)p.dk + ro, acc[1][zs], p.scale, h, in);
         }

@@ -101,6 +101,12 @@ template <typename T> struct MfmaAsm;
             asm volatile(MNEMONIC " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(bq));                                        \
             return d;                                                                                           \
         }                                                                                                       \
+        /* D(vgpr) = A(vgpr) x B(vgpr) */                                                                       \
+        static NNOP_DEV f32x16 qk_first_v(FRAG a, FRAG b) {                                                     \
+            f32x16 d;                                                                                           \
+            asm volatile(MNEMONIC " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));                                         \
+            return d;                                                                                           \
+        }                                                                                                       \
         /* D(vgpr) = A(vgpr) x B(acc file) + C(vgpr), C kept */                                                 \
         static NNOP_DEV f32x16 qk_init(FRAG a, FRAG bq, const f32x16& c) {                                      \
             f32x16 d;                                                                                           \

@@ -60,7 +60,7 @@ inline bool emb_supported(int e) { return e >= 1 && e <= 512 && (e & (e - 1)) ==
 // (the one-wave-per-SIMD kernels copy whole steps of these rows; the padding holds neutral values), and for the problems those
 // kernels take (16-bit, E = 64 / 128) the same two values once more as 2 x 8 elements of T per row (operand fragments)
 inline size_t bwd_rows_padded(const nnop_fa_desc& d) { return (size_t)d.batch * d.qh * (size_t)((d.ql + 63) & ~63); }
-inline bool bwd_has_rcf(const nnop_fa_desc& d) { return d.dtype != NNOP_F32 && (d.emb == 64 || d.emb == 128); }
+inline bool bwd_has_rcf(const nnop_fa_desc& d) { return d.dtype != NNOP_F32 && (d.emb == 64 || d.emb == 128 || d.emb == 256); }
 inline size_t bwd_workspace_bytes(const nnop_fa_desc& d) {
     return bwd_rows_padded(d) * (2 * sizeof(float) + (bwd_has_rcf(d) ? 32 : 0));
 }

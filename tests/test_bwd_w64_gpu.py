@@ -142,3 +142,14 @@ def test_long_sweep(pkg, dev, tune, E):
     d = make_inputs(98, 1, 2, 1, 3072, 3072, E, "bf16", dev)
     check(pkg, d, False, "bf16")
     check(pkg, d, True, "bf16")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("QL,KL,QH,KH,causal,pad", [(256, 256, 2, 2, False, None), (255, 257, 2, 2, False, None), (700, 300, 4, 2, True, "ref"),
+                                                    (515, 515, 6, 2, False, "lens"), (1024, 1024, 2, 1, True, None), (33, 1000, 2, 2, False, "random")])
+def test_e256(pkg, dev, tune, dt, QL, KL, QH, KH, causal, pad):
+    """E = 256 (16-bit): shapes 1 x 1 -- one 32-row block each way -- and the dK/dV pass split into two column halves per key block
+    (every workgroup keeps full-E K / V fragments and half of the accumulators); spill-free where the 32-row kernels of fa_bwd.hpp
+    spilled 126..589 registers at the 256-register cap."""
+    tune(bwd_w64=1)
+    check(pkg, make_inputs(99, 2, QH, KH, QL, KL, 256, dt, dev, pad=pad), causal, dt)

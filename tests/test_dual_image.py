@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import dual_image  # noqa: E402
 
 
-@pytest.mark.parametrize("E", [64, 128])
+@pytest.mark.parametrize("E", [64, 128, 256])
 def test_dual_image_reads_are_correct_and_conflict_free(E):
     assert dual_image.check(E) == {"row": 0, "col": 0}
 
@@ -22,5 +22,5 @@ def test_the_row_swizzles_of_the_forward_images_would_conflict_on_the_transposed
     transposed read share 64-byte bank groups (4-way / 2-way conflicts per 32-lane half); with DualImg's there is none"""
     assert dual_image.col_conflicts_with(128, lambda row: row & 15) >= 2 * 3
     assert dual_image.col_conflicts_with(64, lambda row: (row >> 1) & 7) >= 2 * 1
-    for E in (64, 128):
+    for E in (64, 128, 256):
         assert dual_image.col_conflicts_with(E, lambda row, E=E: dual_image.xor_of(E, row)) == 0

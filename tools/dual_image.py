@@ -30,7 +30,7 @@ def row_bytes(E):
 
 def xor_of(E, row):
     """chunk swizzle of tile row `row` (DualImg::xor_of)"""
-    if E == 128:
+    if E >= 128:                                   # 256-byte rows and longer: the low 4 chunk bits
         return ((row & 3) << 2) | ((row >> 2) & 3)
     if E == 64:
         return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1)
@@ -72,7 +72,7 @@ def row_read_addr(E, lane, zb, ks):
 def col_lane_base(E, lane):
     h, g1, q, p = lane >> 5, (lane >> 4) & 1, (lane >> 2) & 3, lane & 3
     rb = row_bytes(E)
-    qx = q if E == 128 else (q >> 1)
+    qx = q if E >= 128 else (q >> 1)
     return (4 * h + q) * rb + 16 * (4 * qx + ((2 * g1 + (p >> 1)) ^ h)) + 8 * (p & 1)
 
 
@@ -151,5 +151,5 @@ def col_conflicts_with(E, xor_fn, rows=64):
 
 
 if __name__ == "__main__":
-    for E in (64, 128):
+    for E in (64, 128, 256):
         print(E, check(E))
