@@ -408,9 +408,13 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
 #pragma unroll
         for (int zs = 0; zs < ZS; ++zs)
 #pragma unroll
-            for (int eb = 0; eb < EB; ++eb)
+            for (int eb = 0; eb < EB; ++eb) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[y][zs][eb][i] = 0.f;
+                // zeroed HERE: left to itself hipcc sinks the v_accvgpr_writes to the first use -- directly in front of the asm MFMA
+                // that takes the tile as its C operand (VALU write -> MFMA read needs wait states; tools/audit_w64.py, E = 256)
+                asm volatile("" : "+a"(acc[y][zs][eb]));
+            }
 
     if (n_steps > 0) {
         const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -796,7 +800,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
 
         // a wave idles out its last MFMA before it leaves a copy of the loop body (see fa_fwd_w64.hpp: register-allocator copies of
         // accumulator tiles on the exit edges)
-        auto leave_fence = []() { asm volatile(NNOP_FENCE_128 ::: "memory"); };
+        auto leave_fence = []() { asm volatile(NNOP_FENCE_128 ::: "memory"); __builtin_amdgcn_sched_barrier(0); };       // (nothing is scheduled across: the exit edge's register copies stay behind the idle time)
 #if NNOP_BW64_STAMP
         stamp[2] = __builtin_amdgcn_s_memtime();
         stamp[3] = __builtin_amdgcn_s_memrealtime();

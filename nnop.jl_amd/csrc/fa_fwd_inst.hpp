@@ -88,9 +88,10 @@ static int launch_fwd_split(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t
 // 64-rows-per-wave form (fa_fwd_w64.hpp): 4 waves x 64 rows, 16-bit types, E = 64 / 128, plain and masked modes
 template <typename T, int E, int MODE, bool PRE>
 static int launch_fwd_w64(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
-    constexpr int lds = fa_fwd_w64_lds_bytes<T, E>(MODE != 0);
+    constexpr int EV = E == 256 ? 128 : E;                   // E = 256: two 128-column halves of O per block (fa_fwd_w64.hpp)
+    constexpr int lds = fa_fwd_w64_lds_bytes<T, E, EV>(MODE != 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = fa_fwd_w64_kernel<T, E, MODE, PRE>;
+    auto kern = fa_fwd_w64_kernel<T, E, MODE, PRE, EV>;
     static unsigned long long lds_done = 0;
     if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
     FwdParams p;
@@ -103,7 +104,8 @@ static int launch_fwd_w64(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.n_wg = (int)n_wg;
     p.scale = (float)(1.0 / sqrt((double)E));
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds, s, p);
+    if (n_wg * (E / EV) > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg * (E / EV))), dim3(256), lds, s, p);
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
@@ -125,6 +127,13 @@ static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
     // the early exits of launch_fwd: embedding dims outside the tiled set (16-bit E = 256 runs the 32-row tiled kernel)
     if (!(E == 256 && b16) && emb_generic(E)) return kFormGeneric;
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
+    if (b16 && E == 256) {
+        // E = 256: the 64-row form with two 128-column halves of O per block (spill-free; the 32-row form spills 62-152 registers
+        // and measured 214 TFLOP/s at L2048 H8 B2).  No pair bias; masked mode up to 64 Ki keys; a few kv tiles.
+        const int w64 = tune_get(kTuneFwdW64);
+        const bool fits = mode != 2 && (mode == 0 || d.kl <= 64 * kMaxMaskTiles) && (long long)d.kl * E * 2 < (1LL << 32);
+        if (fits && w64 != 0 && d.kl >= 128) return kFormW64;
+    }
     if (b16 && (E == 64 || E == 128)) {
         // 64-row waves (fa_fwd_w64.hpp): 4 waves x 64 rows, one wave per SIMD with the whole register file.  Measured
         // against the 32-row forms after the round-2 schedule work (bf16 / fp16, MI355X, tools/w64_check.py): faster wherever
@@ -156,6 +165,9 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     // Workgroup shape of the 32-row form: 8 waves x 32 rows (256-row workgroups) when that still yields >= one
     // workgroup per CU, else 4 waves x 32 rows so that small problems spread over more CUs.
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
+    if constexpr (sizeof(T) == 2 && E == 256) {
+        if (form == kFormW64) return mode == 0 ? launch_fwd_w64<T, E, 0, false>(d, a, s) : launch_fwd_w64<T, E, 1, false>(d, a, s);    // exact scale only
+    }
     if constexpr (sizeof(T) == 2 && (E == 64 || E == 128)) {
         if (form == kFormW64) {
             // The scale.  DEFAULT: exact -- scale * log2(e) applied in fp32 inside the exponent (one v_fma per logit).  Opt-in

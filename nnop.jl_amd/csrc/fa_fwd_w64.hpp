@@ -191,10 +191,15 @@ template <int J, bool FIRST> NNOP_DEV void dma_piece(u32x4 rsrc, uint32_t voff, 
 // tools/w64_gaps.py), so the streams are dealt out by COST: the smallest per-slot budget `cap` for which a greedy in-order
 // fill places everything inside its window -- a softmax step no later than the slot before the first MFMA that reads the P^T
 // word it completes; a row-max item no earlier than two slots behind the last MFMA that writes the logits it reads.
-template <int E, bool SUM, bool MASKED, int NJ, int LAG> struct W64Plan {
-    static constexpr int KS = E / 16, EB = E / 32, NKF = 2 * KS;
+// NJ2: LDS-DMA pieces per wave and iteration (both tensors); EV: columns of V / O the workgroup handles (E, or E / 2 at E = 256)
+template <int E, bool SUM, bool MASKED, int NJ2, int LAG, int EV = E> struct W64Plan {
+    static constexpr int KS = E / 16, EB = EV / 32, NKF = 2 * KS;
     static constexpr int NX = 2 * NKF, G = 2 * EB + (SUM ? 2 : 0), NY2 = 4 * G, NSLOT = NX + NY2, NYB = NY2 / 2;
     static constexpr int NSTEP = 64 + LAG, NMX = 34;
+    static constexpr int DSTRIDE = NYB + 2 * NJ2 <= NY2 ? 2 : 1;       // a DMA piece every second slot behind the barrier where that fits
+    static_assert(NYB + DSTRIDE * (NJ2 - 1) + 2 <= NY2, "the DMA batch fits behind the barrier");
+    static constexpr bool dma_at(int i) { return i > NYB && (i - NYB - 1) % DSTRIDE == 0 && (i - NYB - 1) / DSTRIDE < NJ2; }   // i: phase-Y slot
+    static constexpr int dma_index(int i) { return (i - NYB - 1) / DSTRIDE; }
     static constexpr int MASK_SLOT = NX + 2;            // masked mode: tile t+1 is masked here, its row max starts behind it
     static constexpr int ADDR_SLOT = NX + 1;            // scalar address arithmetic of the iteration's DMA batch
     int sm_end[NSLOT] = {};                             // softmax steps [sm_end[s-1], sm_end[s]) run in slot s
@@ -210,7 +215,7 @@ template <int E, bool SUM, bool MASKED, int NJ, int LAG> struct W64Plan {
         const bool is_sum = SUM && w < 2;
         int c = 0;
         if (!is_sum && (wp & 1) == 0) c += 8;           // V fragment (two transposed reads) or a K(t+2) fragment
-        if (i > NYB && ((i - NYB) & 1) == 1 && (i - NYB) / 2 < 2 * NJ) c += 24;         // LDS-DMA piece
+        if (dma_at(i)) c += 24;                         // LDS-DMA piece
         return c;
     }
     // fixed work between the MFMA of slot s and the next one (the movable streams share this gap)
@@ -273,23 +278,27 @@ template <int E, bool SUM, bool MASKED, int NJ, int LAG> struct W64Plan {
     }
 };
 
-template <typename T, int E> constexpr int fa_fwd_w64_lds_bytes(bool masked) {
-    return 3 * (RowImg<T, E>::bytes(64) + ColImg<T, E>::bytes(64)) + (masked ? 16 + 8 * kMaxMaskTiles : 0);
+template <typename T, int E, int EV = E> constexpr int fa_fwd_w64_lds_bytes(bool masked) {
+    return 3 * (RowImg<T, E>::bytes(64) + ColImg<T, EV>::bytes(64)) + (masked ? 16 + 8 * kMaxMaskTiles : 0);
 }
 
-template <typename T, int E, int MODE, bool PRE>
+// EV: the columns of V / O this workgroup handles.  EV = E except at E = 256, where the O^T accumulators of 64 rows x 256 columns would
+// be the whole accumulator file: the grid then holds every block twice, each copy contracting Q K^T over all of E (Q fragments: 128
+// registers) but accumulating one 128-column half of O (+33 % MFMA work for a spill-free kernel; the 32-row form spills 62-152).
+template <typename T, int E, int MODE, bool PRE, int EV = E>
 __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
-    static_assert(sizeof(T) == 2 && (E == 64 || E == 128), "16-bit element types, E = 64 or 128");
+    static_assert(sizeof(T) == 2 && ((EV == E && (E == 64 || E == 128)) || (E == 256 && EV == 128)), "16-bit element types, E = 64, 128 or 256 (two 128-column halves)");
     using frag_t = typename Elem<T>::frag;
     using KImg   = RowImg<T, E>;
-    using VImg   = ColImg<T, E>;
+    using VImg   = ColImg<T, EV>;
     using MM     = MfmaAsm<T>;
     constexpr bool kGeneral = MODE != 0;
-    constexpr int BK = 64, KB = 2, KS = E / 16, EB = E / 32, NS = 3;
+    constexpr int BK = 64, KB = 2, KS = E / 16, EB = EV / 32, NS = 3;
     constexpr int KBYTES = KImg::bytes(BK), VBYTES = VImg::bytes(BK);
     constexpr int TILE_BYTES = BK * E * (int)sizeof(T);       // one kv tile in HBM
-    constexpr int NJ = KBYTES / 4096;                         // DMA pieces per wave per tile and tensor
-    static_assert(KBYTES == VBYTES && KBYTES % 4096 == 0, "");
+    constexpr int NJK = KBYTES / 4096, NJV = VBYTES / 4096;   // DMA pieces per wave and tile: K image, V image
+    constexpr int NJ2 = NJK + NJV;
+    static_assert(KBYTES % 4096 == 0 && VBYTES % 4096 == 0 && (EV != E || NJK == NJV), "");
     constexpr int NKF = KB * KS;                              // K fragments per tile (each feeds z = 0, 1)
     constexpr int NVF = 2 * KB * EB;                          // V fragments per tile
     constexpr int NF = NKF + NVF;                             // fragment stream of one iteration
@@ -312,7 +321,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     const int r = lane & 31, h = lane >> 5;
 
     // ---- which (batch, q-head, q-block) ------------------------------------------------------------------------
-    const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_qblk * (p.QH / p.KH));
+    const int vsplit = EV == E ? 0 : (int)blockIdx.x / p.n_wg;     // which column half (E = 256)
+    const int lin = xcd_remap_chunked(EV == E ? (int)blockIdx.x : (int)blockIdx.x % p.n_wg, p.n_wg, p.n_qblk * (p.QH / p.KH));
     int qblk = lin % p.n_qblk;
     const int bh = lin / p.n_qblk;
     if (kGeneral && p.causal) qblk = p.n_qblk - 1 - qblk;    // heaviest q-blocks first
@@ -373,21 +383,26 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // ---- per-lane DMA source offsets inside a tile (the image's layout, applied to the SOURCE) -------------------
     // wave w copies the image bytes [NJ KiB * w, NJ KiB * (w + 1)), piece j = its j-th KiB; lane l the 16 bytes at 16 l.
     // k_voff[j] / v_voff: source byte of that chunk inside the tile MINUS 1024 j (the load's immediate adds it back).
-    static_assert(NJ * 1024 * 4 == KBYTES && NJ <= 4, "four waves x NJ pieces = one image; the immediate is 12 bits");
-    uint32_t k_voff[NJ], v_voff;
+    // More than 4 pieces per wave (E = 256: the K image is 32 KiB) go in groups of 4: the immediate has 12 bits, the next group moves M0.
+    static_assert(NJK * 1024 * 4 == KBYTES && NJV * 1024 * 4 == VBYTES && NJV <= 4 && NJK <= 8, "four waves x NJ pieces = one image");
+    constexpr int NVO = EV == E ? 1 : NJV;                    // EV == E: +1 KiB in the V image = +1 KiB in the source: one offset serves all pieces
+    uint32_t k_voff[NJK], v_voff[NVO];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int off = (wave * NJ + j) * 1024 + lane * 16;  // LDS byte inside the image
+    for (int j = 0; j < NJK; ++j) {
+        const int off = (wave * NJK + j) * 1024 + lane * 16;  // LDS byte inside the image
         const int row = off / KImg::kRowBytes, phys = (off % KImg::kRowBytes) >> 4;
-        k_voff[j] = (uint32_t)(row * KImg::kRowBytes + ((phys ^ KImg::xor_of(row)) << 4) - j * 1024);
-        if (j == 0) {
-            // blocked V image: +1 KiB in the image = +1 KiB in the source for every j (4 blocks = 8 / 4 rows at E = 64 / 128)
-            const int blk = off >> 8, rg = blk / VImg::kEB, eb = blk % VImg::kEB, rr = (off >> 6) & 3, c4 = (off >> 4) & 3;
-            v_voff = (uint32_t)((4 * rg + rr) * VImg::kRowBytes + ((4 * eb + c4) << 4));
-        }
+        k_voff[j] = (uint32_t)(row * KImg::kRowBytes + ((phys ^ KImg::xor_of(row)) << 4) - (j & 3) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < NVO; ++j) {
+        // blocked V image [row >> 2][column block][row & 3][32 columns]; source rows are E elements long, this workgroup's columns
+        // start at vsplit * EV
+        const int off = (wave * NJV + j) * 1024 + lane * 16;
+        const int blk = off >> 8, rg = blk / VImg::kEB, eb = blk % VImg::kEB, rr = (off >> 6) & 3, c4 = (off >> 4) & 3;
+        v_voff[j] = (uint32_t)((4 * rg + rr) * KImg::kRowBytes + ((4 * eb + c4) << 4) + vsplit * EV * (int)sizeof(T) - j * 1024);
     }
     static_assert((1024 / 256) % VImg::kEB == 0 && (4 * (1024 / 256 / VImg::kEB)) * VImg::kRowBytes == 1024, "V image: 1 KiB = whole row groups");
-    const uint32_t wave_off = (uint32_t)(wave * NJ * 1024);
+    const uint32_t wave_off_k = (uint32_t)(wave * NJK * 1024), wave_off_v = (uint32_t)(wave * NJV * 1024);
     const uint32_t kv_bytes = (uint32_t)p.KL * (uint32_t)KImg::kRowBytes;     // one (batch, kv-head) tensor; < 4 GiB (launcher)
     const u32x4 krs = make_rsrc(kp, kv_bytes), vrs = make_rsrc(vp, kv_bytes);
     // Past the last tile the LAST tile is copied again (into a ring slot nobody reads any more) instead of branching
@@ -396,23 +411,23 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     auto tile_off = [&](int t) -> uint32_t { return (uint32_t)(t < n_tiles ? t : n_tiles - 1) * (uint32_t)TILE_BYTES; };
     // piece j of the tile at byte `soff` of the tensor behind `rs`, into the ring slot whose wave share starts at LDS byte `dst`
     auto issue_piece = [&](u32x4 rs, uint32_t soff, uint32_t dst, uint32_t voff, auto jc) {
-        constexpr int j = decltype(jc)::value;
-        dma_piece<j, j == 0>(rs, voff, soff, dst);
+        constexpr int j = decltype(jc)::value;                // piece index inside the tensor's share; groups of 4 per M0
+        dma_piece<(j & 3), (j & 3) == 0>(rs, voff, soff, dst + (uint32_t)((j >> 2) * 4096));        // (the lane's source offset holds the rest)
     };
     auto issue_k = [&](int t, uint32_t slot) {
         const uint32_t so = tile_off(t);
-        static_for<NJ>([&](auto jc) { issue_piece(krs, so, slot, k_voff[decltype(jc)::value], jc); });
+        static_for<NJK>([&](auto jc) { issue_piece(krs, so, slot, k_voff[decltype(jc)::value], jc); });
     };
     auto issue_v = [&](int t, uint32_t slot) {
         const uint32_t so = tile_off(t);
-        static_for<NJ>([&](auto jc) { issue_piece(vrs, so, slot, v_voff, jc); });
+        static_for<NJV>([&](auto jc) { issue_piece(vrs, so, slot, v_voff[NVO == 1 ? 0 : decltype(jc)::value], jc); });
     };
     // Ring slots (LDS byte addresses) as rotating scalars -- no t % 3 arithmetic in the loop:
     //   kA, kB, kC = slots of K(t+1), K(t+2), K(t+3) (= K(t)'s, free);   vA, vB, vC = slots of V(t), V(t+1), V(t+2) (free)
     // Each holds slot + this wave's DMA share (wave_off): the DMA uses it as is, the fragment reads add a lane base that has
     // wave_off subtracted.
-    uint32_t kA = kring + wave_off + 1 * KBYTES, kB = kring + wave_off + 2 * KBYTES, kC = kring + wave_off;
-    uint32_t vA = vring + wave_off, vB = vring + wave_off + 1 * VBYTES, vC = vring + wave_off + 2 * VBYTES;
+    uint32_t kA = kring + wave_off_k + 1 * KBYTES, kB = kring + wave_off_k + 2 * KBYTES, kC = kring + wave_off_k;
+    uint32_t vA = vring + wave_off_v, vB = vring + wave_off_v + 1 * VBYTES, vC = vring + wave_off_v + 2 * VBYTES;
     // byte offsets (inside the tensor) of the tiles the next DMA batch copies: K(t+3), V(t+2), clamped to the last tile
     const uint32_t last_off = (uint32_t)(n_tiles - 1) * (uint32_t)TILE_BYTES;
     uint32_t off_k3 = tile_off(3), off_v2 = tile_off(2);
@@ -454,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             }
         }
     }
-    issue_v(0, vA); issue_k(1, kA); issue_v(1, vB); issue_k(2, kB);      // 4 NJ pieces that may still be in flight below
+    issue_v(0, vA); issue_k(1, kA); issue_v(1, vB); issue_k(2, kB);      // 2 NJ2 pieces that may still be in flight below
     // kPre: -(exponent reference) per query row, broadcast over a 16-register tuple = the initial accumulator of QK^T
     f32x16 negm[2];
     if constexpr (kPre) {
@@ -497,8 +512,8 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // V transposed read (ColImg): image + lane_base + compile-time offsets.
     typedef __attribute__((address_space(3))) const frag_t* lds_frag_p;
     typedef __attribute__((address_space(3))) s16x4* lds_tr_p;
-    const uint32_t k_lane = (uint32_t)(r * KImg::kRowBytes + ((KImg::xor_of(r) ^ h) << 4)) - wave_off;     // ring scalars include wave_off
-    const uint32_t v_lane = (uint32_t)VImg::lane_base(lane) - wave_off;
+    const uint32_t k_lane = (uint32_t)(r * KImg::kRowBytes + ((KImg::xor_of(r) ^ h) << 4)) - wave_off_k;   // ring scalars include wave_off
+    const uint32_t v_lane = (uint32_t)VImg::lane_base(lane) - wave_off_v;
     auto read_kfrag = [&](uint32_t ka, int f) -> frag_t {          // ka = image address + k_lane
         const int kb = f / KS, ks = f % KS;
         return *(lds_frag_p)(uintptr_t)((ka ^ (uint32_t)(ks << 5)) + (uint32_t)(kb * 32 * KImg::kRowBytes));
@@ -578,6 +593,13 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // Rare path: raise the reference; everything accumulated at the old one (O, l) is scaled exactly once, and (kPre) the
     // tile `sc` is re-based onto the new reference.
     auto rescale = [&](const float (&mx)[2], f32x16 (&sc)[2][KB], bool first) {
+        // The fence of this (rare) block carries NO operand: with the accumulator file full (E = 256) hipcc satisfies a tied "+a"
+        // operand by copying the tile through arch VGPRs -- and put the first v_accvgpr_read in FRONT of the statement that was
+        // meant to fence it (tools/audit_w64.py).  An operand-free volatile statement with a memory clobber stays first.
+        if (!first) {
+            asm volatile(NNOP_FENCE_128 ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int z = 0; z < 2; ++z) {
             const float base0 = kPre ? mbase[z] : 0.f;
@@ -588,8 +610,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             if (!first) {                                                 // first tile: O and l are still zero
 #pragma unroll
                 for (int eb = 0; eb < EB; ++eb) {
-                    if (z == 0 && eb == 0) fence_acc_result(oacc[z][eb]);
-                    else acc_after_fence(oacc[z][eb]);
+                    acc_after_fence(oacc[z][eb]);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) oacc[z][eb][i] *= alpha;
                     // back in the accumulator file BEFORE the paths merge: otherwise the merged value is allocated in
@@ -625,18 +646,25 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // ---- prologue, continued: wait for the first tiles, S(0) = K(0) Q^T, its mask and row max -----------------------
     // K(0) and Q landed (every wave's pieces: barrier); the other four tiles of the prologue stay in flight behind the
     // counted wait while S(0) is computed.  The Q fragments pass through the statement.
-    static_assert(4 * NJ == 16 || 4 * NJ == 8, "vmcnt literal below");
-    if constexpr (KS == 8) {
-        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier"
+    static_assert(2 * NJ2 <= 63, "vmcnt literal below");
+    if constexpr (KS == 16) {
+        asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
+                     : "+a"(qf[0][0]), "+a"(qf[0][1]), "+a"(qf[0][2]), "+a"(qf[0][3]), "+a"(qf[0][4]), "+a"(qf[0][5]), "+a"(qf[0][6]), "+a"(qf[0][7])
+                     : [nfl] "n"(2 * NJ2) : "memory");
+        asm volatile("" : "+a"(qf[0][8]), "+a"(qf[0][9]), "+a"(qf[0][10]), "+a"(qf[0][11]), "+a"(qf[0][12]), "+a"(qf[0][13]), "+a"(qf[0][14]), "+a"(qf[0][15]) :: "memory");
+        asm volatile("" : "+a"(qf[1][0]), "+a"(qf[1][1]), "+a"(qf[1][2]), "+a"(qf[1][3]), "+a"(qf[1][4]), "+a"(qf[1][5]), "+a"(qf[1][6]), "+a"(qf[1][7]) :: "memory");
+        asm volatile("" : "+a"(qf[1][8]), "+a"(qf[1][9]), "+a"(qf[1][10]), "+a"(qf[1][11]), "+a"(qf[1][12]), "+a"(qf[1][13]), "+a"(qf[1][14]), "+a"(qf[1][15]) :: "memory");
+    } else if constexpr (KS == 8) {
+        asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
                      : "+a"(qf[0][0]), "+a"(qf[0][1]), "+a"(qf[0][2]), "+a"(qf[0][3]), "+a"(qf[0][4]), "+a"(qf[0][5]),
                        "+a"(qf[0][6]), "+a"(qf[0][7]), "+a"(qf[1][0]), "+a"(qf[1][1]), "+a"(qf[1][2]), "+a"(qf[1][3]),
                        "+a"(qf[1][4]), "+a"(qf[1][5]), "+a"(qf[1][6]), "+a"(qf[1][7])
-                     :: "memory");
+                     : [nfl] "n"(2 * NJ2) : "memory");
     } else {
-        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier"
+        asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
                      : "+a"(qf[0][0]), "+a"(qf[0][1]), "+a"(qf[0][2]), "+a"(qf[0][3]), "+a"(qf[1][0]), "+a"(qf[1][1]),
                        "+a"(qf[1][2]), "+a"(qf[1][3])
-                     :: "memory");
+                     : [nfl] "n"(2 * NJ2) : "memory");
     }
 
 #if NNOP_W64_STAMP
@@ -681,7 +709,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     // ---- one iteration: softmax + PV of tile t on `sc` (row max `mxc` known) beside QK^T of tile t+1 into `sn` ------
     // `need`: in -- tile t must raise a reference first (rescale_test of its row max); out -- the same for tile t+1.
     constexpr int LAG = NNOP_W64_LAG;
-    using Plan = W64Plan<E, kSum, kGeneral, NJ, LAG>;
+    using Plan = W64Plan<E, kSum, kGeneral, NJ2, LAG, EV>;
     auto iteration = [&](int t, int& need_io, f32x16 (&sc)[2][KB], const float (&mxc)[2], f32x16 (&sn)[2][KB], float (&mxn)[2]) {
         if (__builtin_expect(need_io != 0, 0)) rescale(mxc, sc, t == 0);
         float msub[2];
@@ -759,7 +787,6 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         static_assert(Plan::NX == NX && plan.sm_end[Plan::NSLOT - 1] == Plan::NSTEP && plan.mx_end[Plan::NSLOT - 1] == Plan::NMX, "every item placed");
         // the first fragment of K(t+2) is read ahead from the PV slot of V fragment NVF - PF: behind the tile barrier
         static_assert(((NVF - PF) / EB) * G + (kSum ? 2 : 0) + 2 * ((NVF - PF) % EB) >= NYB, "K(t+2) reads behind the barrier");
-        static_assert(NYB + 4 * NJ <= NY2, "the DMA batch fits behind the barrier");
         auto movable = [&](auto sc_) {                            // the slot's share of the two streams
             constexpr int sl = decltype(sc_)::value;
             constexpr int n0 = sl ? plan.sm_end[sl - 1] : 0, n1 = plan.sm_end[sl];
@@ -801,11 +828,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             }
             // the next batch -- K(t+3), V(t+2): 2 NJ pieces -- one piece per odd slot behind the barrier (an LDS-DMA
             // instruction occupies the wave's issue for ~16 cycles; a burst of 2 NJ of them idles the matrix pipe)
-            if constexpr (i > NYB && ((i - NYB) & 1) == 1 && (i - NYB) / 2 < 2 * NJ) {
+            if constexpr (Plan::dma_at(i)) {
 #if !(NNOP_W64_ABL & 1)
-                constexpr int d = (i - NYB) / 2;
-                if constexpr (d < NJ) issue_piece(krs, ksoff, kdst, k_voff[d < NJ ? d : 0], std::integral_constant<int, d>{});
-                else issue_piece(vrs, vsoff, vdst, v_voff, std::integral_constant<int, d - NJ>{});
+                constexpr int d = Plan::dma_index(i);
+                if constexpr (d < NJK) issue_piece(krs, ksoff, kdst, k_voff[d < NJK ? d : 0], std::integral_constant<int, d>{});
+                else issue_piece(vrs, vsoff, vdst, v_voff[NVO == 1 ? 0 : (d >= NJK ? d - NJK : 0)], std::integral_constant<int, d - NJK>{});
 #endif
             }
             if constexpr (is_sum) {
@@ -850,7 +877,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #ifdef NNOP_W64_NO_LEAVE_FENCE            // self-test of tools/audit_w64.py: it must flag the build without the fences
     auto leave_fence = []() {};
 #else
-    auto leave_fence = []() { asm volatile(NNOP_FENCE_128 ::: "memory"); };
+    auto leave_fence = []() { asm volatile(NNOP_FENCE_128 ::: "memory"); __builtin_amdgcn_sched_barrier(0); };       // (nothing is scheduled across: the exit edge's register copies stay behind the idle time)
 #endif
 #if NNOP_W64_STAMP
     stamp[2] = __builtin_amdgcn_s_memtime();
@@ -899,7 +926,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
             ltot = half_swap_sum(lp[z][0] + lp[z][1]);
         }
         const float inv = 1.0f / ltot;                     // ltot == 0 (no visible key) -> NaN rows, as the naive formula gives
-        T* orow = (T*)p.o + ((size_t)bh * p.QL + (qi[z] < p.QL ? qi[z] : p.QL - 1)) * E;
+        T* orow = (T*)p.o + ((size_t)bh * p.QL + (qi[z] < p.QL ? qi[z] : p.QL - 1)) * E + vsplit * EV;
 #pragma unroll
         for (int eb = 0; eb < EB; ++eb) {
             acc_after_fence(oacc[z][eb]);
@@ -928,7 +955,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
 #endif
             }
         }
-        if (qi[z] < p.QL && h == 0) {
+        if (qi[z] < p.QL && h == 0 && vsplit == 0) {
             // residual contract (src/attention.jl:128-129): ms = row max (natural-log units) rounded to T, ls relative to
             // the ROUNDED ms so that the pair stays self-consistent in 16-bit types
             const size_t so = (size_t)bh * p.QL + qi[z];

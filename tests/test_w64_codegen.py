@@ -14,7 +14,7 @@ AUDIT = os.path.join(ROOT, "tools", "audit_w64.py")
 def test_shipped_w64_kernels_pass_the_audit():
     r = subprocess.run([sys.executable, AUDIT, "--only", "fwd"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(": OK") == 16         # {bf16, f16} x {E64, E128} x {plain, masked} x {scale folded into Q, exact}
+    assert r.stdout.count(": OK") == 20         # {bf16, f16} x ({E64, E128} x {plain, masked} x {scale folded into Q, exact} + E256 x {plain, masked})
 
 
 def test_shipped_backward_w64_kernels_pass_the_audit():
@@ -23,7 +23,7 @@ def test_shipped_backward_w64_kernels_pass_the_audit():
     of them: the tiles of the first key block came out wrong, found on the GPU; this model flags that placement)."""
     r = subprocess.run([sys.executable, AUDIT, "--only", "bwd"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(": OK") == 16         # {bf16, f16} x {E64, E128} x {dK/dV, dQ} x {plain, masked}
+    assert r.stdout.count(": OK") == 24         # {bf16, f16} x {E64, E128, E256} x {dK/dV, dQ} x {plain, masked}
 
 
 def test_audit_flags_the_build_without_leave_fences():
