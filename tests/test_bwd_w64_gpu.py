@@ -31,12 +31,16 @@ def check(pkg, d, causal, dt, floor=False):
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("E", [64, 128])
 @pytest.mark.parametrize("which", [1, 2, 3, 4])
-@pytest.mark.parametrize("QL,KL", [(256, 256), (64, 64), (255, 257), (512, 1024), (1100, 300), (33, 1000), (1, 1)])
+@pytest.mark.parametrize("QL,KL", [(64, 64), (255, 257), (512, 1024), (1100, 300), (33, 1000), (1, 1)])
 def test_noncausal(pkg, dev, tune, dt, E, which, QL, KL):
     """which: 1 both passes on the new form (the dQ kernel computes the row constants: no preprocess launch), 2 dK/dV only, 3 dQ only
     (the other pass on csrc/fa_bwd.hpp), 4 both with the separate preprocess launch"""
+    # (tests/test_bwd_gpu.py's structured grid -- E in {16 .. 128} x 4 shapes x 3 dtypes, causal x key padding -- runs through these
+    # kernels by default as well; this file adds what that grid lacks)
     if which != 1 and (QL, KL) not in ((255, 257), (512, 1024)):
         pytest.skip("the mixed combinations on two shapes only")
+    if which == 1 and (QL, KL) in ((255, 257), (512, 1024)) and dt == "f16":
+        pytest.skip("covered in bf16 and by test_bwd_gpu.py")
     tune(bwd_w64=which)
     # a single key: dS = P (dP - delta) cancels to exactly zero in the oracle (tests/util.py, ABS_FLOOR)
     check(pkg, make_inputs(91, 2, 2, 2, QL, KL, E, dt, dev), False, dt, floor=(KL == 1))
@@ -44,9 +48,11 @@ def test_noncausal(pkg, dev, tune, dt, E, which, QL, KL):
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("E", [64, 128])
-@pytest.mark.parametrize("L", [64, 255, 256, 257, 700, 1024])
+@pytest.mark.parametrize("L", [64, 257, 700])
 @pytest.mark.parametrize("pad", [None, "ref"])
 def test_causal(pkg, dev, tune, dt, E, L, pad):
+    if dt == "f16" and pad == "ref":
+        pytest.skip("covered in bf16")
     tune(bwd_w64=1)
     check(pkg, make_inputs(92, 2, 2, 2, L, L, E, dt, dev, pad=pad), True, dt)
 
@@ -65,6 +71,8 @@ def test_causal_rectangular(pkg, dev, tune, dt, E, QL, KL):
 @pytest.mark.parametrize("pad", ["lens", "random", "ref"])
 @pytest.mark.parametrize("causal", [False, True])
 def test_padmask(pkg, dev, tune, dt, E, pad, causal):
+    if dt == "f16" and causal:
+        pytest.skip("covered in bf16")
     tune(bwd_w64=1)
     check(pkg, make_inputs(94, 3, 2, 2, 700, 700, E, dt, dev, pad=pad), causal, dt)
 
@@ -76,6 +84,8 @@ def test_padmask(pkg, dev, tune, dt, E, pad, causal):
 def test_gqa(pkg, dev, tune, dt, E, QH, KH, causal):
     """the dK/dV pass sweeps the q-heads of a kv head in one stream (ragged QL: every head's last step runs into the next head's
     rows, which the padded row constants turn into P = 0)"""
+    if dt == "f16" and (QH, KH) != (8, 2):
+        pytest.skip("covered in bf16")
     tune(bwd_w64=1)
     check(pkg, make_inputs(95, 2, QH, KH, 515, 515, E, dt, dev), causal, dt)
 
@@ -111,7 +121,7 @@ def test_fully_masked_batch_and_dead_rows(pkg, dev, tune, dt, E):
 def test_bitwise_reproducible_and_close_to_the_32_row_form(pkg, dev, tune, dt, E, causal, pad, QH, KH):
     d = make_inputs(97, 2, QH, KH, 1100, 1100, E, dt, dev, pad=pad)
     o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], None, causal=causal, kpad_mask=d["mask"])
-    flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
+    flush = torch.empty(288 * 1024 * 1024, dtype=torch.uint8, device=dev)      # > the 256 MiB Infinity Cache
 
     def bwd():
         g = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], None, causal=causal, kpad_mask=d["mask"])
@@ -136,10 +146,10 @@ def test_bitwise_reproducible_and_close_to_the_32_row_form(pkg, dev, tune, dt, E
 
 @pytest.mark.parametrize("E", [64, 128])
 def test_long_sweep(pkg, dev, tune, E):
-    """many iterations of the ring (L = 3072: 96 / 48 steps per workgroup; the full-size launches of test_baseline_configs_gpu.py
+    """many iterations of the ring (L = 2304: 72 / 36 steps per workgroup; the full-size launches of test_baseline_configs_gpu.py
     go to 512 steps)"""
     tune(bwd_w64=1)
-    d = make_inputs(98, 1, 2, 1, 3072, 3072, E, "bf16", dev)
+    d = make_inputs(98, 1, 2, 1, 2304, 2304, E, "bf16", dev)
     check(pkg, d, False, "bf16")
     check(pkg, d, True, "bf16")
 

@@ -83,90 +83,76 @@ def _run(pkg, dev, dt, c, causal):
         assert_close(name, leaf.grad, ref, dt, kind="grad")
 
 
-# test/attention_tests.jl:6-20  (dt on top = varies fastest, so the oracle cache of a grid point serves its three dtypes)
+# ---- the benchmark's kernels under the reference grids ---------------------------------------------------------------------------
+# The grids are small (<= 24 workgroups of 256 rows): left to itself the launcher sends their forward to the 32-row / split-KV forms.
+# The kernel that carries the headline number is the 64-row forward (csrc/fa_fwd_w64.hpp); the backward of every 16-bit E = 64 / 128
+# problem without a pair bias is the one-wave-per-SIMD form (csrc/fa_bwd_w64.hpp) by default.  `form = "w64"` runs a grid point once
+# more with the 64-row forward FORCED (16-bit types, E = 64 -- and an E = 128 slice the reference does not have, in the causal and
+# GQA grids --, no pair bias: that mode stays on the 32-row kernel); the two 16-bit types alternate over the points (suite time).
+FORMS = ["auto", "w64"]
+
+
+def _w64_applies(dt, E, use_pair, salt):
+    return dt != "f32" and E in (64, 128) and not use_pair and (dt == "f16") == (salt % 2 == 1)
+
+
+# test/attention_tests.jl:6-20  (form, dt on top = vary fastest, so the oracle cache of a grid point serves all its runs)
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("use_padmask", [False, True])
 @pytest.mark.parametrize("use_pair", [False, True])
 @pytest.mark.parametrize("E", [16, 32, 64])
 @pytest.mark.parametrize("QL", [255, 256, 511, 512, 1024])
 @pytest.mark.parametrize("KL", [255, 256, 511, 512, 1024])
-def test_flash_attention_grid(pkg, dev, dt, KL, QL, E, use_pair, use_padmask):
-    if dt == "f16" and E < 64:
+def test_flash_attention_grid(pkg, dev, tune, dt, form, KL, QL, E, use_pair, use_padmask):
+    if form == "w64":
+        if not _w64_applies(dt, E, use_pair, QL + KL + use_padmask) or E != 64:
+            pytest.skip("64-row forward: 16-bit, E = 64, no pair bias")
+        tune(fwd_w64=1, bwd_w64=1)
+    if dt == "f16" and (E < 64 or use_pair) and form == "auto":
         # suite time (round-2 verdict: drop dtype repeats where the kernel form is identical): fp16 and bf16 run the same kernel
-        # templates and differ in the MFMA opcode only; fp16 stays on the E = 64 slice here and on every E in the causal / GQA grids
-        pytest.skip("fp16 at E < 64: same kernel form as bf16")
+        # templates and differ in the MFMA opcode only; fp16 stays on the E = 64 slice without a bias here and on every E in the
+        # causal / GQA grids
+        pytest.skip("fp16 at E < 64 or with a pair bias: same kernel form as bf16")
     H, B = 2, 3
     c = _case(("att", use_padmask, use_pair, E, QL, KL), B, H, H, QL, KL, E, False, use_padmask, use_pair)
     _run(pkg, dev, dt, c, False)
 
 
-# test/causal_attention_tests.jl:6-18
+# test/causal_attention_tests.jl:6-18  (+ E = 128 for the 64-row kernels)
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("use_padmask", [False, True])
 @pytest.mark.parametrize("use_pair", [False, True])
-@pytest.mark.parametrize("E", [16, 32, 64])
+@pytest.mark.parametrize("E", [16, 32, 64, 128])
 @pytest.mark.parametrize("L", [255, 256, 511, 512, 1024])
-def test_causal_flash_attention_grid(pkg, dev, dt, L, E, use_pair, use_padmask):
+def test_causal_flash_attention_grid(pkg, dev, tune, dt, form, L, E, use_pair, use_padmask):
+    if form == "w64":
+        if dt == "f32" or E not in (64, 128) or use_pair:
+            pytest.skip("64-row forward: 16-bit, E = 64 / 128, no pair bias")
+        tune(fwd_w64=1, bwd_w64=1)
+    elif E == 128:
+        pytest.skip("E = 128 is not in the reference's grid: the added slice runs on the 64-row kernels only")
     H, B = 2, 3
     c = _case(("causal", use_padmask, use_pair, E, L), B, H, H, L, L, E, True, use_padmask, use_pair)
     _run(pkg, dev, dt, c, True)
 
 
-# test/gqa_attention_tests.jl:6-19
+# test/gqa_attention_tests.jl:6-19  (+ E = 128 for the 64-row kernels)
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("QH", [4, 6, 8])
 @pytest.mark.parametrize("KVH", [1, 2])
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("E", [32, 64])
+@pytest.mark.parametrize("E", [32, 64, 128])
 @pytest.mark.parametrize("L", [255, 256, 257, 512])
-def test_grouped_query_attention_grid(pkg, dev, dt, L, E, causal, KVH, QH):
-    B = 2
-    c = _case(("gqa", QH, KVH, causal, E, L), B, QH, KVH, L, L, E, causal, False, False)
-    _run(pkg, dev, dt, c, causal)
-
-
-# ---- the benchmark's kernels under the reference grids ---------------------------------------------------------------------------
-# The grids above are small (<= 24 workgroups of 256 rows): the launcher sends their forward to the 32-row / split-KV forms.  The
-# kernel that carries the headline number is the 64-row forward (csrc/fa_fwd_w64.hpp); the backward of every 16-bit E = 64 / 128
-# problem without a pair bias is the one-wave-per-SIMD form (csrc/fa_bwd_w64.hpp) by default.  Here the E = 64 slices of the three
-# grids -- and an E = 128 slice the reference does not have -- run once more with the 64-row forward FORCED (no pair bias: that mode
-# stays on the 32-row kernel), same oracle, same criteria, 16-bit types.
-W64_DTYPES = ["bf16", "f16"]
-
-
-@pytest.mark.parametrize("dt", W64_DTYPES)
-@pytest.mark.parametrize("use_padmask", [False, True])
-@pytest.mark.parametrize("QL", [255, 256, 511, 512, 1024])
-@pytest.mark.parametrize("KL", [255, 256, 511, 512, 1024])
-def test_flash_attention_grid_on_the_64_row_kernels(pkg, dev, tune, dt, KL, QL, use_padmask):
-    if (dt == "f16") != ((QL + KL + use_padmask) % 2 == 1):
-        pytest.skip("the two 16-bit types alternate over the grid points (suite time)")
-    tune(fwd_w64=1, bwd_w64=1)
-    H, B = 2, 3
-    c = _case(("att", use_padmask, False, 64, QL, KL), B, H, H, QL, KL, 64, False, use_padmask, False)
-    _run(pkg, dev, dt, c, False)
-
-
-@pytest.mark.parametrize("dt", W64_DTYPES)
-@pytest.mark.parametrize("use_padmask", [False, True])
-@pytest.mark.parametrize("E", [64, 128])
-@pytest.mark.parametrize("L", [255, 256, 511, 512, 1024])
-def test_causal_grid_on_the_64_row_kernels(pkg, dev, tune, dt, L, E, use_padmask):
-    tune(fwd_w64=1, bwd_w64=1)
-    H, B = 2, 3
-    c = _case(("causal", use_padmask, False, E, L), B, H, H, L, L, E, True, use_padmask, False)
-    _run(pkg, dev, dt, c, True)
-
-
-@pytest.mark.parametrize("dt", W64_DTYPES)
-@pytest.mark.parametrize("QH,KVH", [(4, 1), (6, 2), (8, 2)])
-@pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("E", [64, 128])
-@pytest.mark.parametrize("L", [255, 257, 512])
-def test_gqa_grid_on_the_64_row_kernels(pkg, dev, tune, dt, L, E, causal, KVH, QH):
-    if (dt == "f16") != ((L + QH + causal + E // 64) % 2 == 1):
-        pytest.skip("the two 16-bit types alternate over the grid points (suite time)")
-    tune(fwd_w64=1, bwd_w64=1)
+def test_grouped_query_attention_grid(pkg, dev, tune, dt, form, L, E, causal, KVH, QH):
+    if form == "w64":
+        if not _w64_applies(dt, E, False, L + QH + KVH + causal) or L == 256:
+            pytest.skip("64-row forward: 16-bit, E = 64 / 128; the two types alternate")
+        tune(fwd_w64=1, bwd_w64=1)
+    elif E == 128:
+        pytest.skip("E = 128 is not in the reference's grid: the added slice runs on the 64-row kernels only")
     B = 2
     c = _case(("gqa", QH, KVH, causal, E, L), B, QH, KVH, L, L, E, causal, False, False)
     _run(pkg, dev, dt, c, causal)
