@@ -92,7 +92,12 @@ template <int E, int KIND> struct BwdW64Shape {
     // E = 256: one block each way (the accumulator file holds 128 accumulator + 128 fragment registers of ONE 32-row block), and the
     // dK/dV pass runs as NSPLIT = 2 launches-in-one: each workgroup keeps full-E K / V fragments (S and dP contract over all of E)
     // but only half of the dK^T / dV^T accumulators -- 6 product-units instead of 4, spill-free.
-    static constexpr int ZS = E == 256 ? 1 : ((kDQ || E == 64) ? 2 : 1);       // stationary 32-row blocks per wave
+    // dK/dV at E = 128 (kVLds): 64 keys per wave as at E = 64 -- every streamed fragment feeds two MFMAs, half the LDS read and LDS-DMA
+    // traffic per MFMA of the 1 x 2 shape it replaces -- although their dK^T / dV^T accumulators are the whole accumulator file (256):
+    // the K fragments live in the arch VGPRs (64) and the V fragments are read from an LDS image of the workgroup's V rows, as a
+    // second fragment stream beside the dO rows.
+    static constexpr bool kVLds = !kDQ && E == 128;
+    static constexpr int ZS = E == 256 ? 1 : ((kDQ || E == 64 || kVLds) ? 2 : 1);       // stationary 32-row blocks per wave
     static constexpr int ZT = E == 256 ? 1 : 2 / ZS;                           // streamed 32-row blocks per step
     static constexpr int NSPLIT = (!kDQ && E == 256) ? 2 : 1;
     static constexpr int NYP = kDQ ? 1 : 2;                   // Y products
@@ -110,12 +115,16 @@ template <int E, int KIND> struct BwdW64Shape {
     static constexpr int TB = ZS * (KS + RCM);                // X slots per (product, zt): [row-constant MFMA,] KS steps, each x ZS
     static constexpr int NY = NFY * ZS, NX = 2 * ZT * TB, NSLOT = NY + NX;             // MFMA slots
     static constexpr int WG_ROWS = 4 * SW;
+    static constexpr int VIMG = kVLds ? WG_ROWS * RB : 0;     // LDS image of the workgroup's V rows (behind the ring)
+    static constexpr int NVB = kVLds ? ZS * KS : 0, PFB = 3, RFB = 4;      // V fragment stream of an iteration, its read-ahead / ring
+    // dP slot of V fragment b = 2 ks + zs (relative to the iteration): behind phase Y, the S tiles and dP's row-constant MFMAs
+    static constexpr int vb_slot(int b) { return NY + TB + ZS * RCM + b; }
     static_assert(IMG % 4096 == 0 && NJ >= 1 && NJ <= 4, "four waves x NJ pieces = one image; 12-bit immediate");
     static_assert(SLOT % (RB > 256 ? RB : 256) == 0, "XOR-addressed fragment reads: slot bases aligned to a row / 256 bytes");
 };
 template <typename T, int E, int KIND> constexpr int fa_bwd_w64_lds_bytes(bool masked) {
     using SH = BwdW64Shape<E, KIND>;
-    return SH::NS * SH::SLOT + (masked ? (SH::kDQ ? 16 + 8 * kMaxMaskTiles : 16) : 0);
+    return SH::NS * SH::SLOT + SH::VIMG + (masked ? (SH::kDQ ? 16 + 8 * kMaxMaskTiles : 16) : 0);
 }
 
 // ---- the slot plan ------------------------------------------------------------------------------------------------------------
@@ -164,6 +173,8 @@ template <int E, int KIND, bool MASKED, int LAG, int PF> struct BwdW64Plan {
         for (int tq = 0; tq < 2 * SH::ZT * SH::RCM; ++tq)
             if (s == rc_read_slot(tq)) c += 12;
         if (s == BAR_SLOT + 1) c += SH::kDQ ? 24 : 60;
+        for (int b = 0; b < SH::NVB; ++b)
+            if (s == SH::vb_slot(b) - SH::PFB) c += 16;       // V fragment read-ahead (ds_read_b128 + xor)
         for (int d = 0; d < SH::NPB; ++d)
             if (s == dma_slot(d)) c += 40 + ((d % SH::NJ == 0 || d >= 2 * SH::NJ) ? 14 : 0);
         return c;
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
     bool svalid[ZS];
 #pragma unroll
     for (int zs = 0; zs < ZS; ++zs) svalid[zs] = sidx[zs] < SL;
-    uint64_t* const vbits = reinterpret_cast<uint64_t*>(smem + NS * SLOT + 16);
+    uint64_t* const vbits = reinterpret_cast<uint64_t*>(smem + NS * SLOT + SH::VIMG + 16);
     int n_steps = U;
     if constexpr (kGeneral && !kDQ) {
         if (mp) {
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             }
             // (no __syncthreads_or: its static LDS word would sit in front of the dynamic segment, whose base the XOR-addressed
             // fragment reads need 256-byte aligned)
-            int* flag = reinterpret_cast<int*>(smem + NS * SLOT);
+            int* flag = reinterpret_cast<int*>(smem + NS * SLOT + SH::VIMG);
             if (tid == 0) *flag = 0;
             __syncthreads();
             if (any) *flag = 1;
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         }
     }
     if constexpr (kGeneral && kDQ) {
-        int* slot = reinterpret_cast<int*>(smem + NS * SLOT);
+        int* slot = reinterpret_cast<int*>(smem + NS * SLOT + SH::VIMG);
         const int nk = n_steps * RT < p.KL ? n_steps * RT : p.KL;
         if (mp) {
             const int last = kpad_scan(mp, p.KL, nk, vbits, kMaxMaskTiles, slot, tid, 256);
@@ -477,14 +488,32 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         auto rotate_slots = [&]() { sY = sM; sM = sX; sX = sF; sF = sD; sD = sY; };
 
         // ---- prologue: the stationary fragments first (X(0) needs them and step 0), then steps 0, 1, 2 ------------------------------
-        frag_t b1[ZS][KS], b2[ZS][KS];
+        constexpr bool kVLds = SH::kVLds;
+        frag_t b1[ZS][KS], b2[kVLds ? 1 : ZS][kVLds ? 1 : KS];
 #pragma unroll
         for (int zs = 0; zs < ZS; ++zs)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                b1[zs][ks] = load_q_frag<frag_t>(b1p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
-                b2[zs][ks] = load_q_frag<frag_t>(b2p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
+                if constexpr (kVLds) {
+                    b1[zs][ks] = *reinterpret_cast<const frag_t*>(b1p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);      // arch VGPRs
+                } else {
+                    b1[zs][ks] = load_q_frag<frag_t>(b1p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
+                    b2[zs][ks] = load_q_frag<frag_t>(b2p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
+                }
             }
+        // kVLds: this wave's 64 V rows -> its quarter of the V image (DualImg row layout; 16 KiB = 16 pieces in groups of four per
+        // M0).  Only this wave reads them, so its own vmcnt (the prologue's wait below) is all the synchronisation they need.  Rows
+        // past KL are outside the descriptor: whatever lands there stays on the lanes of keys whose results are discarded.
+        const uint32_t vimg0 = lds0 + (uint32_t)(NS * SLOT);
+        if constexpr (kVLds) {
+            const u32x4 rsv = make_rsrc(b2p, (uint32_t)SL * (uint32_t)RB);
+            const uint32_t vsoff = (uint32_t)s0wg * (uint32_t)RB;
+            static_for<16>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const uint32_t vo = (uint32_t)(Img::src_of((wave * 16 + j) * 1024 + lane * 16) - (j & 3) * 1024);
+                dma_piece<(j & 3), (j & 3) == 0>(rsv, vo, vsoff, vimg0 + (uint32_t)(wave * 16384 + (j >> 2) * 4096));
+            });
+        }
         issue_step(sM);
         advance_dma();
         issue_step(sX);
@@ -507,7 +536,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         // dK/dV: B operand of the row-constant MFMAs: (1, 1, 1, 0 ...) in lane half 0 (it sums the three 16-bit terms of the fp32
         // constant), zeros in lane half 1.  Opaque, and in the accumulator file like the other stationary operands.
         // (E = 256: the accumulator file is full -- 128 accumulator + 128 fragment registers -- and it lives in the arch VGPRs)
-        constexpr bool kBonesV = E == 256;
+        constexpr bool kBonesV = E == 256 || kVLds;
         frag_t bones;
         if constexpr (!kDQ) {
 #pragma unroll
@@ -554,6 +583,12 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             const s16x8 v8 = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
             return __builtin_bit_cast(frag_t, v8);
         };
+        // kVLds: V fragment b = 2 ks + zs (B operand of dP) from the V image: the row read of DualImg on this wave's rows
+        const uint32_t v_lane = vimg0 + (uint32_t)(wave * 64 * RB + Img::row_lane_base(lane));
+        auto read_vb = [&](int b) -> frag_t {
+            const int ks = b / ZS, zs = b % ZS;
+            return *(lds_frag_p)(uintptr_t)((v_lane ^ (uint32_t)(ks << 5)) + (uint32_t)(zs * 32 * RB));
+        };
         // row constants of tile (product, zt) as an A fragment (see rc_lane0 / rc_lane1); rca = slot + rc_lane<product>
         auto read_rcf = [&](uint32_t rca, int zt) -> frag_t { return *(lds_frag_p)(uintptr_t)(rca + (uint32_t)(zt * 1024)); };
 
@@ -598,7 +633,13 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
 
         // ---- the stationary fragments and step 0 have landed (every wave's pieces: barrier); steps 1 and 2 stay in flight -- the
         // barrier of iteration 0 waits for step 1 with the same counted wait as every other iteration -----------------------------------
-        if constexpr (KS == 16) {
+        if constexpr (kVLds) {
+#pragma unroll
+            for (int zs = 0; zs < ZS; ++zs)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) landed(b1[zs][ks]);
+            asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier" :: [nfl] "n"(2 * NPB) : "memory");
+        } else if constexpr (KS == 16) {
             static_assert(ZS == 1, "");
             asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
                          : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b1[0][4]), "+a"(b1[0][5]), "+a"(b1[0][6]), "+a"(b1[0][7])
@@ -647,9 +688,14 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
 #pragma unroll
                         for (int zs = 0; zs < ZS; ++zs) {
                             f32x16& d = (prod ? dA : sA)[zs][zt];
-                            const frag_t& bq = (prod ? b2 : b1)[zs][ks];
-                            if (kDQ && ks == 0) d = prod ? MM::qk_init(a, bq, ndl[zs]) : MM::qk_first(a, bq);
-                            else MM::qk_acc(d, a, bq);
+                            if constexpr (kVLds) {
+                                const frag_t bq = prod ? read_vb(ks * ZS + zs) : b1[zs][ks];
+                                MM::qk_acc_v(d, a, bq);
+                            } else {
+                                const frag_t& bq = (prod ? b2 : b1)[zs][ks];
+                                if (kDQ && ks == 0) d = prod ? MM::qk_init(a, bq, ndl[zs]) : MM::qk_first(a, bq);
+                                else MM::qk_acc(d, a, bq);
+                            }
                         }
                     }
                 }
@@ -694,6 +740,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             uint32_t rcimg[2] = {0, 0};                                // step u+1: row-constant fragments
             if constexpr (!kDQ) { rcimg[0] = opaque(sX + rc_lane0); rcimg[1] = opaque(sX + rc_lane1); }
             frag_t rcf[2 * ZT];
+            frag_t vb[kVLds ? SH::RFB : 1];                             // kVLds: V fragment ring (B operand of dP)
             uint32_t dst = 0, soff = 0, srow = 0;                      // this iteration's DMA batch
 
             // element n of step u: tile n / 16 = (zs, zt), accumulator register i = n % 16.
@@ -761,9 +808,14 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                         d = rc_tile(rcf[tq]);                           // the tile starts as its row constants
                     } else {
                         constexpr int g = Plan::x_frag(j), ks = g % KS;
-                        const frag_t& bq = (prod ? b2 : b1)[zs][ks];
-                        if constexpr (kDQ && ks == 0) d = prod ? MM::qk_init(fr[(NFY + g) % RF], bq, ndl[zs]) : MM::qk_first(fr[(NFY + g) % RF], bq);
-                        else MM::qk_acc(d, fr[(NFY + g) % RF], bq);
+                        if constexpr (kVLds) {
+                            if constexpr (prod == 0) MM::qk_acc_v(d, fr[(NFY + g) % RF], b1[zs][ks]);
+                            else MM::qk_acc_v(d, fr[(NFY + g) % RF], vb[(ks * ZS + zs) % SH::RFB]);
+                        } else {
+                            const frag_t& bq = (prod ? b2 : b1)[zs][ks];
+                            if constexpr (kDQ && ks == 0) d = prod ? MM::qk_init(fr[(NFY + g) % RF], bq, ndl[zs]) : MM::qk_first(fr[(NFY + g) % RF], bq);
+                            else MM::qk_acc(d, fr[(NFY + g) % RF], bq);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -771,6 +823,12 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                     static_for<2 * ZT>([&](auto tc) {
                         constexpr int tq = decltype(tc)::value;
                         if constexpr (i == Plan::rc_read_slot(tq)) rcf[tq] = read_rcf(rcimg[tq / ZT], tq % ZT);
+                    });
+                }
+                if constexpr (kVLds) {
+                    static_for<SH::NVB>([&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        if constexpr (i == SH::vb_slot(b) - SH::PFB) vb[b % SH::RFB] = read_vb(b);
                     });
                 }
                 if constexpr (i == Plan::BAR_SLOT + 1) {

@@ -107,6 +107,9 @@ template <typename T> struct MfmaAsm;
             asm volatile(MNEMONIC " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));                                         \
             return d;                                                                                           \
         }                                                                                                       \
+        static NNOP_DEV void qk_acc_v(f32x16& d, FRAG a, FRAG b) {                                              \
+            asm volatile(MNEMONIC " %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));                                         \
+        }                                                                                                       \
         /* D(vgpr) = A(vgpr) x B(acc file) + C(vgpr), C kept */                                                 \
         static NNOP_DEV f32x16 qk_init(FRAG a, FRAG bq, const f32x16& c) {                                      \
             f32x16 d;                                                                                           \
