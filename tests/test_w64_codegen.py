@@ -27,7 +27,7 @@ def test_shipped_backward_w64_kernels_pass_the_audit():
 
 
 def test_audit_flags_the_build_without_leave_fences():
-    r = subprocess.run([sys.executable, AUDIT, "--flags", "-DNNOP_W64_NO_LEAVE_FENCE=1"], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, AUDIT, "--only", "fwd", "--flags", "-DNNOP_W64_NO_LEAVE_FENCE=1"], capture_output=True, text=True)
     assert r.returncode == 1 and "before the MFMA writing it is done" in r.stdout, r.stdout + r.stderr
 
 
@@ -44,11 +44,11 @@ def test_schedule_of_the_generated_loop_stays_balanced():
     per = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"Li(\d+)ELi0ELb1\w*: .*? ([\d.]+) per MFMA", r.stdout)}
     assert set(per) == {64, 128}, r.stdout
     assert per[64] <= 46.5 and per[128] <= 43.0, per
-    # the backward kernels (csrc/fa_bwd_w64.hpp; round 3, measured 49.8 / 50.6 / 44.8 / 38.2 cycles per algorithmic MFMA): one compile
+    # the backward kernels (csrc/fa_bwd_w64.hpp; round 3, measured 49.8 / 50.6 cycles per algorithmic MFMA at E = 64, 38.2 in the dQ pass at E = 128): one compile
     r = subprocess.run([sys.executable, gaps, "IDF16b", "--bwd"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     got = {(int(m.group(1)), int(m.group(2))): float(m.group(3))
            for m in re.finditer(r"Li(\d+)ELi(\d)ELi0E\w*: .*? ([\d.]+) per MFMA", r.stdout)}
-    lim = {(64, 0): 45.0, (64, 1): 49.5, (128, 0): 46.0, (128, 1): 39.5}        # (E, kind: 0 dK/dV, 1 dQ), plain mode
+    lim = {(64, 0): 45.0, (64, 1): 49.5, (128, 0): 40.0, (128, 1): 39.5, (256, 0): 45.0, (256, 1): 44.0}        # (E, kind: 0 dK/dV, 1 dQ), plain mode
     assert set(got) == set(lim), r.stdout
     assert all(got[k] <= lim[k] for k in lim), got
