@@ -279,6 +279,7 @@ def main():
         bdesc = pkg._lib.FaDesc(dtype={"f32": 0, "f16": 1, "bf16": 2}[dtn], emb=E, ql=L, kl=L, qh=q.shape[1], kh=k.shape[1],
                                 batch=q.shape[0], causal=int(causal), emb_k=0, emb_v=0, kl_v=0, kh_v=0)
         kn_kv, kn_q = pkg._lib.bwd_kernels(bdesc, False, kpad is not None)
+        fused_pre = kn_kv.startswith("fa_bwd_w64") and kn_q.startswith("fa_bwd_w64")      # csrc/fa_bwd_inst.hpp: p.fused
         f_bwd = 2.5 * f_fwd                               # algorithmic (S and dP counted once: SURVEY.md section 8(d))
         t_pre, t_kv, t_q = stage_t[1], max(stage_t[3] - stage_t[1], 1e-9), max(t_all - stage_t[3], 1e-9)
         extra["bwd_tflops"] = round(world * f_bwd / t_all / 1e12, 2)
@@ -287,7 +288,9 @@ def main():
             "frac": round(f_bwd / t_all / 1e12 / PEAK_TFLOPS[dtn], 4), "avg_call_us": round(t_all * 1e6, 2), "iters": nb,
             "flops_per_call": int(f_bwd),
             "kernels": [
-                {"name": "fa_bwd_pre_kernel", "avg_us": round(t_pre * 1e6, 2), "bound": "hbm"},
+                ({"name": "fa_bwd_pre_kernel", "avg_us": round(t_pre * 1e6, 2), "bound": "hbm"} if not fused_pre else
+                 {"name": "(no preprocess launch: fused into the dQ kernel; this is the time of the call with no kernel in it)",
+                  "avg_us": round(t_pre * 1e6, 2)}),
                 # products per pass: dK/dV = S, dP, dV, dK (2 of the 2.5 fwd-units); dQ = S, dP recomputed + dQ (0.5 algorithmic, 1.5 executed)
                 {"name": kn_kv, "avg_us": round(t_kv * 1e6, 2), "executed_tflops": round(2.0 * f_fwd / t_kv / 1e12, 1),
                  "executed_frac": round(2.0 * f_fwd / t_kv / 1e12 / PEAK_TFLOPS[dtn], 4)},

@@ -11,7 +11,8 @@ STEPS=100; [ "$CFG" != "c2" ] && STEPS=10
 BENCH="python3 bench.py --config $CFG --steps $STEPS --warmup 5 --no-cpu-baseline --no-bwd $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_traced.json 2> $OUT/trace.err
 i=0
-for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
+# (at most 4 counters per pass, so that no pass is silently split into several)
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
   i=$((i+1)); rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc$i -- $BENCH > /dev/null 2> $OUT/pmc$i.err
 done
 python3 - "$OUT" "$CFG" <<'PY'
