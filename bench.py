@@ -327,7 +327,7 @@ def main():
             cuts = [B * i // nch for i in range(nch + 1)]
             sl = [slice(cuts[i], cuts[i + 1]) for i in range(nch)]
             o_ch = [o[c] for c in sl]
-            full_ch = [torch.empty((world,) + tuple(oc.shape), dtype=o.dtype, device=dev) for oc in o_ch]
+            full_ch = [torch.empty((world * oc.shape[0],) + tuple(oc.shape[1:]), dtype=o.dtype, device=dev) for oc in o_ch]
             kp_ch = [None if kpad is None else kpad[c] for c in sl]
             step_chunk = lambda i: pkg.fa_fwd_into(o_ch[i], ms[sl[i]], ls[sl[i]], q[sl[i]], k[sl[i]], v[sl[i]], causal=causal, kpad_mask=kp_ch[i])
             ov = lambda: pkg.shard.forward_with_overlapped_gather(step_chunk, o_ch, full_ch)

@@ -19,9 +19,11 @@ static std::once_flag g_tune_once;
 static void tune_init() {
     static const char* const names[kTuneCount] = {"NNOP_FWD_SPLIT", "NNOP_FWD_NW",       "NNOP_FWD_W64",
                                                   "NNOP_BWD_BIG7",  "NNOP_NORM_BWD_CAP", "NNOP_BWD_NW",
-                                                  "NNOP_FWD_EXACT_SCALE", "NNOP_BWD_W64", "NNOP_BWD_STAGES"};
+                                                  "NNOP_FWD_EXACT_SCALE", "NNOP_BWD_W64", nullptr};
+    // (kTuneBwdStages has no environment variable: it makes the backward INCOMPLETE -- a measurement aid that only the test hook
+    // nnop_debug_set can switch on, csrc/nnop_debug.h)
     for (int k = 0; k < kTuneCount; ++k) {
-        const char* s = getenv(names[k]);
+        const char* s = names[k] ? getenv(names[k]) : nullptr;
         __atomic_store_n(&g_tune[k], (s && *s) ? atoi(s) : -1, __ATOMIC_RELAXED);
     }
 }

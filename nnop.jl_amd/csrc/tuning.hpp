@@ -21,7 +21,7 @@ enum TuneKey {
     kTuneBwdNW,          // NNOP_BWD_NW      16-bit E <= 64 backward: waves per workgroup (4 | 8)
     kTuneFwdExactScale,  // NNOP_FWD_EXACT_SCALE  64-row forward: 0 = fold scale*log2e into Q (rounded to T; opt-in, faster), 1 / auto = apply it in fp32 per logit
     kTuneBwdW64,         // NNOP_BWD_W64     one-wave-per-SIMD backward (fa_bwd_w64.hpp): 0 never, 1 both passes, 2 dK/dV only, 3 dQ only, 4 both + separate preprocess launch
-    kTuneBwdStages,      // NNOP_BWD_STAGES  measurement only: which passes of the tiled backward run (bit mask: 1 preprocess, 2 dK/dV, 4 dQ)
+    kTuneBwdStages,      // (no environment variable; nnop_debug_set only)  measurement only: which passes of the tiled backward run (bit mask: 1 preprocess, 2 dK/dV, 4 dQ)
     kTuneCount
 };
 

@@ -104,7 +104,8 @@ def forward_with_overlapped_gather(step_chunk, o_chunks, full_chunks, group=None
     its own stream, ordered behind the launch by an event -- while chunk i+1 computes on the launch stream.
 
     step_chunk(i): launches the forward of chunk i on the current stream (writes o_chunks[i]);
-    full_chunks[i]: [world, *o_chunks[i].shape] destination.  Returns after every gather has completed on the current stream."""
+    full_chunks[i]: the destination, rank r's chunk at rows [r * n, (r + 1) * n) for n = o_chunks[i].shape[0] (the concatenated form
+    both RCCL and gloo accept).  Returns after every gather has completed on the current stream."""
     import torch.distributed as dist
     works = []
     for i in range(len(o_chunks)):

@@ -163,3 +163,27 @@ def test_e256(pkg, dev, tune, dt, QL, KL, QH, KH, causal, pad):
     spilled 126..589 registers at the 256-register cap."""
     tune(bwd_w64=1)
     check(pkg, make_inputs(99, 2, QH, KH, QL, KL, 256, dt, dev, pad=pad), causal, dt)
+
+
+@pytest.mark.parametrize("E", [64, 128])
+def test_misaligned_workspace_takes_the_fallback(pkg, dev, tune, E):
+    """The fragment form of the row constants is written with 16-byte stores and copied by LDS-DMA: with a workspace that is not
+    16-byte aligned the dK/dV pass falls back to the 32-row kernel (the dQ pass keeps the new form, with the separate preprocess).
+    Same results either way."""
+    d = make_inputs(90, 2, 4, 2, 300, 300, E, "bf16", dev)
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], None, causal=True, kpad_mask=None)
+    nbytes = pkg.bwd_workspace_bytes(d["q"], d["k"], d["v"], causal=True)
+    raw = torch.empty(nbytes + 64, dtype=torch.uint8, device=dev)
+    outs = []
+    for off in (0, 8):
+        ws = raw[off:off + nbytes]
+        assert ws.data_ptr() % 16 == off
+        dq, dk, dv = torch.empty_like(d["q"]), torch.empty_like(d["k"]), torch.empty_like(d["v"])
+        pkg.fa_bwd_into(dq, dk, dv, None, ws, d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=True)
+        torch.cuda.synchronize()
+        outs.append((dq, dk, dv))
+    rq, rk, rv, _ = oracle_bwd(d, True)
+    for dq, dk, dv in outs:
+        assert_close("dq", dq, rq, "bf16", kind="grad")
+        assert_close("dk", dk, rk, "bf16", kind="grad")
+        assert_close("dv", dv, rv, "bf16", kind="grad")

@@ -45,10 +45,10 @@ assert torch.equal(full2, o)
 o2 = torch.empty_like(q); ms2 = torch.empty(B, QH, L, dtype=q.dtype, device=dev); ls2 = torch.empty_like(ms2)
 sl = [slice(0, 1), slice(1, 2)]
 o_ch = [o2[c] for c in sl]
-full_ch = [torch.empty((1,) + tuple(x.shape), dtype=x.dtype, device=dev) for x in o_ch]
+full_ch = [torch.empty_like(x) for x in o_ch]                 # world size 1: [1 * n, ...]
 pkg.shard.forward_with_overlapped_gather(lambda i: pkg.fa_fwd_into(o_ch[i], ms2[sl[i]], ls2[sl[i]], q[sl[i]], k[sl[i]], v[sl[i]], causal=True), o_ch, full_ch)
 torch.cuda.synchronize()
-assert torch.equal(torch.cat([f[0] for f in full_ch], dim=0), o)
+assert torch.equal(torch.cat(full_ch, dim=0), o)
 t = torch.tensor([1.5, 2.5], device=dev, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the timing reduction of bench.py
 dist.barrier()

@@ -78,3 +78,57 @@ def test_sharded_forward_world2_gloo(cfg):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+def _worker_overlap(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # weak scaling as bench.py --gather runs it: every rank has its own batch; the batch is cut into chunks and chunk i's
+        # all-gather is issued (async) right behind its forward, while chunk i+1 computes
+        B, H, L, E = 4, 2, 12, 16
+        g = torch.Generator().manual_seed(100 + rank)
+        tq, tk, tv = (torch.randn(B, H, L, E, generator=g, dtype=torch.float64) for _ in range(3))
+        o = torch.empty_like(tq)
+        sl = [slice(0, 2), slice(2, 4)]
+        o_ch = [o[c] for c in sl]
+        full_ch = [torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype) for x in o_ch]
+
+        def step_chunk(i):
+            o_ch[i].copy_(_oracle_attn(tq[sl[i]], tk[sl[i]], tv[sl[i]], causal=True))
+
+        pkg.shard.forward_with_overlapped_gather(step_chunk, o_ch, full_ch)
+        mine = _oracle_attn(tq, tk, tv, causal=True)
+        n = [x.shape[0] for x in o_ch]
+        got = torch.cat([f[rank * n[i]:(rank + 1) * n[i]] for i, f in enumerate(full_ch)], dim=0)
+        # the other rank's rows arrive too: compare them with its own recomputation (same seed rule)
+        g2 = torch.Generator().manual_seed(100 + (1 - rank))
+        oq, ok_, ov = (torch.randn(B, H, L, E, generator=g2, dtype=torch.float64) for _ in range(3))
+        theirs = _oracle_attn(oq, ok_, ov, causal=True)
+        got_other = torch.cat([f[(1 - rank) * n[i]:(2 - rank) * n[i]] for i, f in enumerate(full_ch)], dim=0)
+        q.put((rank, bool(torch.equal(got, mine)) and bool(torch.allclose(got_other, theirs, rtol=1e-12, atol=1e-12))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gather_world2_gloo():
+    """`shard.forward_with_overlapped_gather` (bench.py --gather, round-2 verdict item 5c) with two ranks: every chunk's gather is
+    complete and correct on both ranks when the call returns."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
