@@ -373,45 +373,62 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
     // Either from the preprocess launch, or (p.fused: both passes run in this form) computed HERE, which saves that launch: the wave
     // holds the rows anyway -- delta = sum_e dO o over the lane pair (l, l + 32) that shares a row -- and writes them in fragment
     // form for the dK/dV kernel, which then runs BEHIND this one (src/attention_bwd.jl:163-197 is the reference's preprocess).
+    // (fused: the loads are issued HERE, in front of the stationary fragments and the first LDS-DMA batches, and consumed behind
+    // them -- computing right away would put a full memory latency in front of everything else the prologue has to fetch)
     float rc_nl[ZS], rc_nd[ZS];
+    frag_t rc_do[kDQ ? ZS : 1][kDQ ? KS : 1], rc_o[kDQ ? ZS : 1][kDQ ? KS : 1];
+    T rc_m[ZS], rc_l[ZS];
     if constexpr (kDQ) {
 #pragma unroll
         for (int zs = 0; zs < ZS; ++zs) {
             const bool in = sidx[zs] < SL;
-            float nlv, ndv;
+            const size_t row = (size_t)bh_s * p.QL + sidx_c[zs];
+            const T* drow = (const T*)p.d_o + row * E;
+            // the dO fragments: compiler-visible loads (they are both the stationary operand of dP -- moved to the accumulator file
+            // below -- and, fused, one factor of delta: one fetch serves both)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) rc_do[zs][ks] = *reinterpret_cast<const frag_t*>(drow + 16 * ks + 8 * h);
             if (p.fused) {
-                const size_t row = (size_t)bh_s * p.QL + sidx_c[zs];
                 const T* orow = (const T*)p.o + row * E;
-                const T* drow = (const T*)p.d_o + row * E;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) rc_o[zs][ks] = *reinterpret_cast<const frag_t*>(orow + 16 * ks + 8 * h);
+                rc_m[zs] = ((const T*)p.ms)[row];
+                rc_l[zs] = ((const T*)p.ls)[row];
+            } else {
+                const size_t ro = (size_t)bh_s * p.QLs + sidx_c[zs];
+                rc_nl[zs] = in ? p.nl[ro] : -INFINITY;
+                rc_nd[zs] = in ? p.delta[ro] : 0.f;                                      // the workspace holds -delta
+            }
+        }
+    }
+    auto finish_rc = [&]() {
+        if constexpr (kDQ) {
+            if (!p.fused) return;
+#pragma unroll
+            for (int zs = 0; zs < ZS; ++zs) {
                 float part = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const frag_t a = *reinterpret_cast<const frag_t*>(drow + 16 * ks + 8 * h);
-                    const frag_t bq = *reinterpret_cast<const frag_t*>(orow + 16 * ks + 8 * h);
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) part += to_f32(a[j]) * to_f32(bq[j]);
-                }
+                    for (int j = 0; j < 8; ++j) part += to_f32(rc_do[zs][ks][j]) * to_f32(rc_o[zs][ks][j]);
                 const float dl = half_swap_sum(part);
-                const float m = to_f32(((const T*)p.ms)[row]), l = to_f32(((const T*)p.ls)[row]);
-                nlv = -(m * kLog2e + __builtin_amdgcn_logf(l)) / c2;                    // v_log_f32 = log2
-                ndv = -dl;
+                const float m = to_f32(rc_m[zs]), l = to_f32(rc_l[zs]);
+                float nlv = -(m * kLog2e + __builtin_amdgcn_logf(l)) / c2;               // v_log_f32 = log2
+                float ndv = -dl;
                 if (!(l > 0.f) || !(nlv == nlv) || m == -INFINITY) { nlv = -INFINITY; ndv = 0.f; }
-                if (!in) { nlv = -INFINITY; ndv = 0.f; }
+                if (!(sidx[zs] < SL)) { nlv = -INFINITY; ndv = 0.f; }
                 if (p.rcf && sidx[zs] < p.QLs && h == 0) {              // rows QL .. QLs-1: the neutral padding
                     typedef T t8 __attribute__((ext_vector_type(8)));
                     t8* dst = reinterpret_cast<t8*>(p.rcf) + 2 * ((size_t)bh_s * p.QLs + sidx[zs]);
                     dst[0] = rc_split3<T>(nlv);
                     dst[1] = rc_split3<T>(ndv);
                 }
-            } else {
-                const size_t ro = (size_t)bh_s * p.QLs + sidx_c[zs];
-                nlv = in ? p.nl[ro] : -INFINITY;
-                ndv = in ? p.delta[ro] : 0.f;                                            // the workspace holds -delta
+                rc_nl[zs] = nlv;
+                rc_nd[zs] = ndv;
             }
-            rc_nl[zs] = nlv;
-            rc_nd[zs] = ndv;
         }
-    }
+    };
+    if (n_steps == 0) finish_rc();                           // no loop: the fragment form is still owed to the dK/dV kernel
     // ---- accumulators, stationary fragments (accumulator file) ---------------------------------------------------------------
     f32x16 acc[NYP][ZS][EB];
 #pragma unroll
@@ -498,7 +515,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                     b1[zs][ks] = *reinterpret_cast<const frag_t*>(b1p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);      // arch VGPRs
                 } else {
                     b1[zs][ks] = load_q_frag<frag_t>(b1p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
-                    b2[zs][ks] = load_q_frag<frag_t>(b2p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
+                    if constexpr (kDQ) b2[zs][ks] = rc_do[zs][ks];           // already requested (row constants above)
+                    else b2[zs][ks] = load_q_frag<frag_t>(b2p + (size_t)sidx_c[zs] * E + 16 * ks + 8 * h);
                 }
             }
         // kVLds: this wave's 64 V rows -> its quarter of the V image (DualImg row layout; 16 KiB = 16 pieces in groups of four per
@@ -520,6 +538,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         advance_dma();
         issue_step(sF);
         advance_dma();
+        finish_rc();
         // dQ: the query's row constants are per lane: nl2 = c2 * nl (exponent offset), -delta as the initial accumulator of dP
         float nl2[ZS];
         f32x16 ndl[ZS];

@@ -26,7 +26,7 @@ for c in sys.argv[1:] or ["bf16:64:4096:4:4:4"]:
     for _ in range(n): run()
     e1.record(); torch.cuda.synchronize()
     wall = e0.elapsed_time(e1) / n * 1e3
-    for kind, t, H, rows_wg, mf in (("dK/dV", dk, KH, 256 if E == 64 else 128, 8 * (E // 16)), ("dQ", dq, QH, 256, 6 * (E // 16))):
+    for kind, t, H, rows_wg, mf in (("dK/dV", dk, KH, 256 if E <= 128 else 128, 8 * (E // 16)), ("dQ", dq, QH, 256 if E <= 128 else 128, 6 * (E // 16))):
         nb = L // rows_wg
         rows = t.reshape(B * H, nb, rows_wg, E)[:, :, 0, :].contiguous().view(torch.int64)[..., :7].reshape(-1, 7).cpu().double()
         tt, rr, ns = rows[:, 0:6:2], rows[:, 1:6:2], rows[:, 6]
