@@ -25,9 +25,15 @@
 //   * three-stage software pipeline over the streamed steps: iteration u runs Y(u-1), then X(u+1), with the element-wise work of
 //     step u dealt out over all of their MFMA slots by issue cost.  The three stages touch disjoint registers (two sets of
 //     score tiles, two sets of P / dS fragments), so nothing inside an iteration waits for anything else inside it.
-//   * wave shapes (ZS stationary 32-row blocks per wave x ZT streamed 32-row blocks per step, ZS ZT = 2 so that a step is two
-//     score tiles): dK/dV E = 64: 2 x 1 (64 keys per wave: each streamed fragment feeds two MFMAs), E = 128: 1 x 2 (the
-//     accumulators of 64 keys would be the whole accumulator file); dQ: 2 x 1.
+//   * wave shapes (ZS stationary 32-row blocks per wave x ZT streamed 32-row blocks per step): 2 x 1 up to E = 128 -- 64 stationary
+//     rows per wave, so that each streamed fragment feeds two MFMAs.  dK/dV at E = 128 fills the accumulator file with accumulators
+//     alone (256): its K fragments live in the arch VGPRs and its V fragments are a second fragment stream from an LDS image of the
+//     workgroup's V rows (BwdW64Shape::kVLds).  E = 256: 1 x 1, and dK/dV as two workgroups per key block that each accumulate one
+//     128-column half of dK^T / dV^T (NSPLIT).
+//   * row constants: dQ has them per lane (fma(s, c2, nl2); -delta as dP's initial accumulator).  dK/dV has them per accumulator
+//     REGISTER: they enter the score tiles through the matrix pipe, as one extra contraction step of (hi, mid, lo) 16-bit terms
+//     against (1, 1, 1, 0 ...) -- "rcf".  When both passes run in this form the dQ kernel computes them in its prologue (no
+//     preprocess launch) and the dK/dV kernel runs behind it.
 //
 // Modes: 0 plain / 1 masked (causal, key padding, ragged streamed length).  The pair-bias modes stay on fa_bwd.hpp.
 #pragma once
