@@ -121,6 +121,10 @@ template <int E, int KIND> struct BwdW64Shape {
     static constexpr int TB = ZS * (KS + RCM);                // X slots per (product, zt): [row-constant MFMA,] KS steps, each x ZS
     static constexpr int NY = NFY * ZS, NX = 2 * ZT * TB, NSLOT = NY + NX;             // MFMA slots
     static constexpr int WG_ROWS = 4 * SW;
+    // E = 64 (the wave's issue is the bound there): the XOR-ed lane bases of the fragment reads are computed once per iteration (KS row
+    // bases in slot 1, 2 EBA column bases when phase Y has issued its last read) instead of one v_xor per read.  (At E = 128, where the
+    // kernels are power-bound, the same change measured +-0.2 % and is not used.)
+    static constexpr bool kBases = E == 64 && !kDQ;            // (dQ at E = 64 has too few reads per iteration for it to pay)
     static constexpr int VIMG = kVLds ? WG_ROWS * RB : 0;     // LDS image of the workgroup's V rows (behind the ring)
     static constexpr int NVB = kVLds ? ZS * KS : 0, PFB = 3, RFB = 4;      // V fragment stream of an iteration, its read-ahead / ring
     // dP slot of V fragment b = 2 ks + zs (relative to the iteration): behind phase Y, the S tiles and dP's row-constant MFMAs
@@ -170,7 +174,7 @@ template <int E, int KIND, bool MASKED, int LAG, int PF> struct BwdW64Plan {
         int c = 0;
         if (s == BAR_SLOT) c += 8;
         const int f = slot_frag(s % NSLOT);
-        if (f >= 0) c += ((f + PF) % SH::NF < SH::NFY ? 24 : 16) + 2;              // two transposed reads / one ds_read_b128, xor, wait
+        if (f >= 0) c += ((f + PF) % SH::NF < SH::NFY ? 24 : 16) + 2 - (SH::kBases ? 4 : 0);   // two transposed reads / one ds_read_b128, xor, wait
         if (s == NSLOT) c += 24 + 18 + 16 + (MASKED ? 30 : 0);                     // ring rotation, loop control, image bases, mask test
         return c;
     }
@@ -179,6 +183,8 @@ template <int E, int KIND, bool MASKED, int LAG, int PF> struct BwdW64Plan {
         for (int tq = 0; tq < 2 * SH::ZT * SH::RCM; ++tq)
             if (s == rc_read_slot(tq)) c += 12;
         if (s == BAR_SLOT + 1) c += SH::kDQ ? 24 : 60;
+        if (SH::kBases && s == 1) c += 4 * SH::KS;
+        if (SH::kBases && s == SH::NY + 1) c += 8 * SH::EBA;
         for (int b = 0; b < SH::NVB; ++b)
             if (s == SH::vb_slot(b) - SH::PFB) c += 16;       // V fragment read-ahead (ds_read_b128 + xor)
         for (int d = 0; d < SH::NPB; ++d)
@@ -608,6 +614,20 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             const s16x8 v8 = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
             return __builtin_bit_cast(frag_t, v8);
         };
+        // the same reads from precomputed bases (kBases): rb[ks] = ra ^ (ks << 5), cb[2 eb + s] = ca ^ (eb << 6 | s << 5)
+        auto read_row_b = [&](const uint32_t (&rb)[KS], int g) -> frag_t {
+            const int prod = g / (ZT * KS), zt = (g / KS) % ZT, ks = g % KS;
+            return *(lds_frag_p)(uintptr_t)(rb[ks] + (uint32_t)(prod * IMG + zt * 32 * RB));
+        };
+        auto read_col_b = [&](const uint32_t (&cb)[2 * EB], int f) -> frag_t {
+            const int y = f / (2 * ZT * EB), kk = (f / EB) % (2 * ZT), eb = f % EB;
+            const int img = kDQ ? 0 : (y == 0 ? IMG : 0);
+            const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(uintptr_t)(cb[2 * eb] + (uint32_t)(img + 16 * kk * RB)));
+            const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_p)(uintptr_t)(cb[2 * eb + 1] + (uint32_t)(img + (16 * kk + 8) * RB)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 v8 = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+            return __builtin_bit_cast(frag_t, v8);
+        };
         // kVLds: V fragment b = 2 ks + zs (B operand of dP) from the V image: the row read of DualImg on this wave's rows
         const uint32_t v_lane = vimg0 + (uint32_t)(wave * 64 * RB + Img::row_lane_base(lane));
         auto read_vb = [&](int b) -> frag_t {
@@ -742,6 +762,15 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             for (int f = 0; f < PF; ++f) fr[f] = read_col(ca0, f);
         }
 
+        constexpr bool kBases = SH::kBases;
+        uint32_t cbase[2 * EB], rbase[KS];                  // (kBases) this iteration's column bases / row bases
+        auto set_cbase = [&](uint32_t slot) {
+            const uint32_t ca = opaque(slot + col_lane);
+#pragma unroll
+            for (int j = 0; j < 2 * EB; ++j) { cbase[j] = ca ^ (uint32_t)(((j >> 1) << 6) | ((j & 1) << 5)); pin(cbase[j]); }
+        };
+        if constexpr (kBases) set_cbase(sY);
+
         // ---- one iteration: Y(u-1) on the fragments `fp`, X(u+1) into (sn, dn), element-wise work of step u: (sc, dc) -> `fw` -----
         using Plan = BwdW64Plan<E, KIND, kGeneral, LAG, PF>;
         auto iteration = [&](int u, f32x16 (&sc)[ZS][ZT], f32x16 (&dc)[ZS][ZT], f32x16 (&sn)[ZS][ZT], f32x16 (&dn)[ZS][ZT],
@@ -807,9 +836,16 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
             // fragment read PF ahead of stream position f (wraps into the next iteration's column fragments)
             auto read_ahead = [&](auto fc) {
                 constexpr int g = decltype(fc)::value + PF;
-                if constexpr (g < NFY) fr[g % RF] = read_col(cimg, g);
-                else if constexpr (g < NF) fr[g % RF] = read_row(rimg, g - NFY);
-                else fr[g % RF] = read_col(cimg2, g - NF);
+                if constexpr (kBases) {
+                    // cbase: the columns of step u-1 until phase Y has issued its last read (slot NY + 1 re-bases it to step u)
+                    if constexpr (g < NFY) fr[g % RF] = read_col_b(cbase, g);
+                    else if constexpr (g < NF) fr[g % RF] = read_row_b(rbase, g - NFY);
+                    else fr[g % RF] = read_col_b(cbase, g - NF);
+                } else {
+                    if constexpr (g < NFY) fr[g % RF] = read_col(cimg, g);
+                    else if constexpr (g < NF) fr[g % RF] = read_row(rimg, g - NFY);
+                    else fr[g % RF] = read_col(cimg2, g - NF);
+                }
             };
 
             static_for<NSLOT>([&](auto ic) {
@@ -856,6 +892,11 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
                         if constexpr (i == SH::vb_slot(b) - SH::PFB) vb[b % SH::RFB] = read_vb(b);
                     });
                 }
+                if constexpr (kBases && i == 1) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) { rbase[ks] = rimg ^ (uint32_t)(ks << 5); pin(rbase[ks]); }
+                }
+                if constexpr (kBases && i == NY + 1) set_cbase(sM);     // every column read of step u-1 has been issued (slot (NFY - PF) ZS)
                 if constexpr (i == Plan::BAR_SLOT + 1) {
                     dst = sD;
                     soff = d_off;
