@@ -224,7 +224,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    const int lin  = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk);      // chunk = one (batch, kv-head)
+    const int lin  = (kPair && !kStaged) ? xcd_remap_heads((int)blockIdx.x, p.n_blk, p.KH, p.n_wg / p.KH)
+                                         : xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk);      // chunk = one (batch, kv-head)
     const int kblk = lin % p.n_blk;
     const int bk   = lin / p.n_blk;
     const int b    = bk / p.KH;
@@ -518,7 +519,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk * (p.QH / p.KH));
+    int lin = (kPair && !kStaged) ? xcd_remap_heads((int)blockIdx.x, p.n_blk, p.QH, p.n_wg / p.QH)
+                                  : xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk * (p.QH / p.KH));
     int qblk = lin % p.n_blk;
     const int bh = lin / p.n_blk;
     if (p.causal) qblk = p.n_blk - 1 - qblk;

@@ -339,4 +339,25 @@ NNOP_DEV int xcd_remap_chunked(int id, int n, int chunk) {
     return ((s / chunk) * 8 + x) * chunk + (s % chunk);
 }
 
+// Pair-bias kernels (gather straight from the reference layout [B][KL][QL][QH], head fastest): the `nh` heads of one (batch, block)
+// read the SAME cache lines -- 2 bytes of every 2 nh -- so they go to the same XCD in consecutive dispatch slots (ids x, x + 8, ...
+// of that XCD): one L2 then fetches each line once for all heads instead of every head's XCD fetching it again.  Returns the
+// linear index in the kernels' usual (batch, head, block) order.  Bijective for every n_units; the last n_units % 8 units keep the
+// plain order.
+NNOP_DEV int xcd_remap_heads(int id, int n_blk, int nh, int n_units) {
+    const int full = n_units & ~7;
+    int unit, head;
+    if (id < full * nh) {
+        const int x = id & 7, s = id >> 3;
+        unit = (s / nh) * 8 + x;
+        head = s % nh;
+    } else {
+        const int rel = id - full * nh;
+        unit = full + rel / nh;
+        head = rel % nh;
+    }
+    const int b = unit / n_blk, blk = unit - b * n_blk;
+    return (b * nh + head) * n_blk + blk;
+}
+
 }  // namespace nnop

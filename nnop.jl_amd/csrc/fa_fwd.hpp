@@ -144,7 +144,8 @@ __global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const 
 #endif
 
     // ---- which (batch, q-head, q-block) -------------------------------------------------
-    int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_qblk * (p.QH / p.KH));
+    int lin = kPair ? xcd_remap_heads((int)blockIdx.x, p.n_qblk, p.QH, p.n_wg / p.QH)
+                    : xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_qblk * (p.QH / p.KH));
     int qblk = lin % p.n_qblk;
     const int bh = lin / p.n_qblk;
     if (p.causal) qblk = p.n_qblk - 1 - qblk;              // heaviest q-blocks first
