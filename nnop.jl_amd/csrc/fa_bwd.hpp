@@ -183,10 +183,17 @@ template <typename T, int E> struct BwdImgs {
 template <typename T, int E, int NW> constexpr bool fa_bwd_single() { return sizeof(T) == 2 && ((E > 64 && NW == 7) || E > 128); }
 
 // dK/dV kernel: which of the workgroup's K / V fragments live in registers for the whole kernel (else: LDS row images)
-template <typename T, int E, int MODE> constexpr bool fa_bwd_dkdv_vregs() { return E <= 64; }
+// fp32 E = 128 (one wave per SIMD, 512 registers): K and V fragments (64 registers each) beside the 128 accumulator registers --
+// with the images out of LDS a 4-wave workgroup (every SIMD of the CU) fits with double-buffered tiles; the 2-wave form with both
+// images in LDS left half the SIMDs idle (24 % of the fp32 peak)
+#ifndef NNOP_F32_E128_REGS
+#define NNOP_F32_E128_REGS 1
+#endif
+template <typename T, int E> constexpr bool fa_bwd_f32_wide() { return NNOP_F32_E128_REGS && sizeof(T) == 4 && E == 128; }
+template <typename T, int E, int MODE> constexpr bool fa_bwd_dkdv_vregs() { return E <= 64 || (NNOP_F32_E128_REGS == 2 && fa_bwd_f32_wide<T, E>()); }
 template <typename T, int E, int MODE, int NW = 8> constexpr bool fa_bwd_dkdv_kregs() {
     // E = 128: only the 8-wave form (the 4-wave masked kernel spills 25 registers with K on top and measured 2 % slower)
-    return E <= 64 || (NNOP_DKDV_KREGS128 && sizeof(T) == 2 && E == 128 && MODE <= 1 && NW == 8);
+    return E <= 64 || (NNOP_DKDV_KREGS128 && sizeof(T) == 2 && E == 128 && MODE <= 1 && NW == 8) || fa_bwd_f32_wide<T, E>();
 }
 // with K out of LDS the streamed tiles fit twice even at 7 / 8 waves
 template <typename T, int E, int NW, int MODE> constexpr bool fa_bwd_dkdv_single() {
@@ -485,7 +492,7 @@ constexpr int kMaxMaskTilesBwd = 1024;       // key padding: one 64-bit validity
 // images every tile)?  16-bit: E <= 64 always; E = 128 in the plain / masked modes (252-256 registers, no spills; the
 // pair-bias modes would spill ~50) -- which also frees 112 KiB of LDS: those kernels are double-buffered and run 8 waves.
 template <typename T, int E, int MODE> constexpr bool fa_bwd_dq_qregs() {
-    return sizeof(T) == 2 ? (E <= 64 || (E == 128 && MODE <= 1)) : E <= 32;
+    return sizeof(T) == 2 ? (E <= 64 || (E == 128 && MODE <= 1)) : (E <= 32 || fa_bwd_f32_wide<T, E>());
 }
 template <typename T, int E, int NW, int BK, int MODE>
 constexpr int fa_bwd_dq_lds_bytes() {

@@ -15,9 +15,9 @@ template <typename T, int E> struct BwdCfg {
     static constexpr bool kF32 = sizeof(T) == 4;
     // fp32 at E=128 keeps K,V (dkdv) / Q,dO (dq) in LDS instead of registers: fewer waves, smaller tiles
     // (16-bit E = 256: 2 waves, single-buffered tiles -- what fits 160 KiB of LDS)
-    static constexpr int NW_KV = ((kF32 && E > 64) || E > 128) ? 2 : 4;
+    static constexpr int NW_KV = ((kF32 && E > 64 && !fa_bwd_f32_wide<T, E>()) || E > 128) ? 2 : 4;
     static constexpr int BQ    = (kF32 || E > 64) ? 32 : 64;
-    static constexpr int NW_Q  = ((kF32 && E > 64) || E > 128) ? 2 : 4;
+    static constexpr int NW_Q  = ((kF32 && E > 64 && !fa_bwd_f32_wide<T, E>()) || E > 128) ? 2 : 4;
     // 16-bit E = 128, large grids: 7 waves (224 keys / queries per workgroup) with single-buffered tiles ->
     // ~2 waves per SIMD instead of 1 (LDS-limited); small grids keep 4 waves (finer quantization over 256 CUs)
     static constexpr bool kBig7 = !kF32 && E == 128;

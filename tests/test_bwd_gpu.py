@@ -153,3 +153,26 @@ def test_e128_seven_wave_backward_form(pkg, dev, dt, causal, tune):
     for thr in (1, 100000000):
         tune(bwd_big7=thr)
         check_bwd(pkg, d, causal, dt)
+
+
+@pytest.mark.parametrize("causal,pad,pair", [(False, None, False), (True, None, False), (False, "lens", False), (True, "random", False),
+                                             (False, "ref", True), (True, None, True)])
+def test_f32_e128_four_wave_register_form(pkg, dev, causal, pad, pair):
+    """fp32 E = 128 backward (csrc/fa_bwd.hpp, fa_bwd_f32_wide): 4 waves per workgroup, one per SIMD, K fragments (dK/dV) / Q and dO
+    fragments (dQ) in registers beside the accumulators -- the > 256-register mode.  Several 128-key / 128-query blocks, GQA 4/2,
+    ragged lengths; against the oracle, and bitwise equal over repeated launches with the caches flushed in between (no atomics:
+    a hazard or race in the wide register allocation would show here, a tolerance check can miss it)."""
+    d = make_inputs(61, 2, 4, 2, 709, 645, 128, "f32", dev, pad=pad, pair=pair)
+    check_bwd(pkg, d, causal, "f32")
+    flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], d["pair"], causal=causal, kpad_mask=d["mask"])
+    runs = []
+    for _ in range(3):
+        flush.fill_(1)
+        g = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], d["pair"], causal=causal, kpad_mask=d["mask"])
+        torch.cuda.synchronize()
+        runs.append(g)
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            if a is not None:
+                assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
