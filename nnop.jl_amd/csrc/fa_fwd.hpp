@@ -96,7 +96,7 @@ struct FwdParams {
 // MODE 1: masked  -- causal and/or key padding and/or ragged KL
 // MODE 2: pair    -- masked + additive pair bias
 template <typename T, int E, int NW, int BK, int MODE, int QB>
-__global__ __launch_bounds__(NW * 64, QB == 2 ? 1 : 2) void fa_fwd_kernel(const FwdParams p) {
+__global__ __launch_bounds__(NW * 64, (QB == 2 || (sizeof(T) == 4 && E >= 256)) ? 1 : 2) void fa_fwd_kernel(const FwdParams p) {
     using frag_t = typename Elem<T>::frag;
     using KImg   = RowImg<T, E>;
     using VImg   = ColImg<T, E>;

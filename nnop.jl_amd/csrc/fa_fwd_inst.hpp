@@ -125,7 +125,7 @@ static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
     const bool b16 = d.dtype != NNOP_F32;
     const int E = d.emb;
     // the early exits of launch_fwd: embedding dims outside the tiled set (16-bit E = 256 runs the 32-row tiled kernel)
-    if (!(E == 256 && b16) && emb_generic(E)) return kFormGeneric;
+    if (E != 256 && emb_generic(E)) return kFormGeneric;
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
     if (b16 && E == 256) {
         // E = 256: the 64-row form with two 128-column halves of O per block (spill-free; the 32-row form spills 62-152 registers
@@ -230,11 +230,10 @@ template <typename T> static int launch_fwd_generic(const nnop_fa_desc& d, const
 }
 
 template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
-    if constexpr (sizeof(T) == 2) {
-        // E = 256, 16-bit: the 32-row tiled kernel (32-key tiles; it spills some registers at the 256-register cap and is still
-        // ~50x the plain-HIP path).  fp32 E = 256 does not fit LDS and stays on fa_generic.hpp.
-        if (d.emb == 256) return launch_fwd_e<T, 256>(d, a, s);
-    }
+    // E = 256: 16-bit -- the 64-row form (two column halves), or the 32-row tiled kernel with 32-key tiles for what that form does not
+    // take (pair bias, short / very long key axes).  fp32 -- the 32-row tiled kernel, 4 waves with the whole register file each (O^T
+    // 128 + Q fragments 128 registers; K / V rings of 32-key tiles = 128 KiB of LDS); its BACKWARD does not fit and stays on fa_generic.hpp.
+    if (d.emb == 256) return launch_fwd_e<T, 256>(d, a, s);
     if (emb_generic(d.emb)) return launch_fwd_generic<T>(d, a, s);
     switch (d.emb) {
         case 16:  return launch_fwd_e<T, 16>(d, a, s);

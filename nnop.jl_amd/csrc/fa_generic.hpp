@@ -5,8 +5,8 @@
 // every other power of two from 1 to 512 runs here: plain HIP, one wave per row, fp32 arithmetic, no matrix cores, the same
 // contract (causal top-left aligned, key padding, grouped-query heads, pair bias and dpair, ragged lengths, residuals ms / ls
 // per src/attention.jl:128-129, a row without a visible key gives NaN in o and zero gradients).  Correctness path, not a
-// fast one (1-7 TFLOP/s).  16-bit E = 256 does NOT come here: the launchers send it to the tiled kernels (which spill at
-// that size but are ~40x faster); fp32 E = 256 does.
+// fast one (1-7 TFLOP/s).  E = 256 does NOT come here in the 16-bit types (the one-wave-per-SIMD kernels run it, DESIGN.md
+// section 6) nor for the fp32 FORWARD (the 32-row tiled kernel); the fp32 E = 256 backward does.
 //
 //   forward  : wave = one query row; a lane scores one key of the 64-key tile (dot product over E from its own K row, the Q row
 //              broadcast from LDS), online softmax with wave reductions, then O += p_k * V[k] with lane = embedding column.
