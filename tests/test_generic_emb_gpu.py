@@ -44,11 +44,12 @@ def test_through_the_public_entry_point(pkg, dev):
     assert_close("dv", v.grad, rv, "bf16", kind="grad")
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
 @pytest.mark.parametrize("causal", [False, True])
 def test_e256_tiled_kernels_larger_shape_and_reproducibility(pkg, dev, dt, causal):
-    """16-bit E = 256 runs on the tiled MFMA kernels (32-key tiles, 2-wave single-buffered backward; they spill at the
-    256-register cap): a multi-tile, multi-workgroup shape with GQA and a ragged key length, and bitwise-equal repeat launches."""
+    """E = 256 on the MFMA kernels -- 16-bit: the one-wave-per-SIMD forms (csrc/fa_fwd_w64.hpp, fa_bwd_w64.hpp); fp32: the 32-row tiled
+    FORWARD with the whole register file per wave (its backward is the plain-HIP path, fed with the tiled forward's residuals): a
+    multi-tile, multi-workgroup shape with GQA and a ragged key length, and bitwise-equal repeat launches."""
     d = make_inputs(21, 2, 4, 2, 389, 517, 256, dt, dev, pad="lens")
     outs = []
     for _ in range(2):
