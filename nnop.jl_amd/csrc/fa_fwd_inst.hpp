@@ -105,7 +105,25 @@ static int launch_fwd_w64(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     p.n_wg = (int)n_wg;
     p.scale = (float)(1.0 / sqrt((double)E));
     if (n_wg * (E / EV) > 0x7fffffffLL) return NNOP_ERR_SHAPE;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg * (E / EV))), dim3(256), lds, s, p);
+    // Persistent form (fa_fwd_w64.hpp): 256 workgroups that each walk `persist` blocks of a static, balanced list instead of one
+    // workgroup per block -- on a 256-CU device, when the list divides: (batch x q-head) columns in eighths (one per XCD), a power-
+    // of-two number of q-blocks per column, whole steps of 32 blocks per XCD, and more than one step.
+    long long grid = n_wg * (E / EV);
+    if constexpr (EV == E && MODE == 1) {
+        const long long bh = (long long)d.batch * d.qh;
+        const int n = p.n_qblk;
+        const long long per_xcd = (bh / 8) * n;
+        // (auto: under a causal mask without key padding -- there the static list balances exactly and measured +3..4 % at E = 128
+        // L 8192-16384, +23 % at E = 64 L4096 H16 B4; equal-work blocks gain nothing (+-0.3 %), and per-batch key lengths make a
+        // static list 15 % SLOWER than the dispatcher's dynamic order: C4)
+        const int knob = tune_get(kTuneFwdPersist);
+        if ((knob == 1 || (knob < 0 && d.causal && !a.kpad)) && device_cu_count() == 256 && bh % 8 == 0 && (n & (n - 1)) == 0 &&
+            per_xcd % 32 == 0 && per_xcd / 32 >= 2 && per_xcd / 32 <= (1 << 24)) {
+            p.persist = (int)(per_xcd / 32);
+            grid = 256;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, p);
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 

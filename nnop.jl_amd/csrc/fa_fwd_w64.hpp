@@ -289,7 +289,7 @@ template <typename T, int E, int EV = E> constexpr int fa_fwd_w64_lds_bytes(bool
 // be the whole accumulator file: the grid then holds every block twice, each copy contracting Q K^T over all of E (Q fragments: 128
 // registers) but accumulating one 128-column half of O (+33 % MFMA work for a spill-free kernel; the 32-row form spills 62-152).
 template <typename T, int E, int MODE, bool PRE, int EV = E>
-__global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p_arg) {
     static_assert(sizeof(T) == 2 && ((EV == E && (E == 64 || E == 128)) || (E == 256 && EV == 128)), "16-bit element types, E = 64, 128 or 256 (two 128-column halves)");
     using frag_t = typename Elem<T>::frag;
     using KImg   = RowImg<T, E>;
@@ -323,12 +323,43 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    // ---- which (batch, q-head, q-block) ------------------------------------------------------------------------
+    // ---- persistent form (p.persist = blocks per workgroup; 0: one block per workgroup, the grid holds them all) ----------------------
+    // A 512-register, 96-KiB-of-LDS workgroup owns its CU, and the hand-over to the next one costs ~8-10 us of an idle CU per block
+    // (in-kernel stamps, tools/w64_stamp.py: the CUs hold a workgroup 90.5 % of the launch at C3, 93.7 % at the C5 shard).  With
+    // 256 workgroups that each walk a static list of blocks the hand-over is one barrier.  The list: XCD x (= blockIdx % 8, the
+    // observed round-robin dispatch -- a speed assumption only) owns the (batch, q-head) columns [x BH/8, (x+1) BH/8), so its 32
+    // workgroups stream the same K / V through one L2 as before; the XCD's blocks, columns in order and q-blocks DESCENDING inside a
+    // column, are dealt out 32 at a time, alternately forwards and backwards over the XCD's workgroups -- under a causal mask a
+    // workgroup's q-blocks (n-1-c, c, ...) then sum to the same work every two steps, and all workgroups end together.
+    constexpr bool kPersist = kGeneral && EV == E;          // masked-mode kernels of E = 64 / 128 only: elsewhere the loop folds away
+    const int n_steps_pers = (kPersist && p_arg.persist > 0) ? p_arg.persist : 1;
+    for (int pstep = 0; pstep < n_steps_pers; ++pstep) {
+    // The parameters are re-read from the kernel-argument segment for every block (through a pointer the compiler cannot see
+    // through): kept live across the block loop they cost ~25 scalar registers that the hand-placed loop needs (hipcc spilled 3-15).
+    typedef const FwdParams __attribute__((address_space(4))) * params_cp;
+    params_cp pp = (params_cp)__builtin_amdgcn_kernarg_segment_ptr();
+    if constexpr (kPersist) asm volatile("" : "+s"(pp));
+    FwdParams p_blk = p_arg;
+    if constexpr (kPersist) {
+        p_blk.o = pp->o; p_blk.ms = pp->ms; p_blk.ls = pp->ls; p_blk.q = pp->q; p_blk.k = pp->k; p_blk.v = pp->v; p_blk.kpad = pp->kpad;
+        p_blk.QL = pp->QL; p_blk.KL = pp->KL; p_blk.QH = pp->QH; p_blk.KH = pp->KH; p_blk.B = pp->B; p_blk.causal = pp->causal;
+        p_blk.n_qblk = pp->n_qblk; p_blk.n_wg = pp->n_wg; p_blk.scale = pp->scale; p_blk.persist = pp->persist;
+    }
+    const FwdParams& p = p_blk;
     const int vsplit = EV == E ? 0 : (int)blockIdx.x / p.n_wg;     // which column half (E = 256)
-    const int lin = xcd_remap_chunked(EV == E ? (int)blockIdx.x : (int)blockIdx.x % p.n_wg, p.n_wg, p.n_qblk * (p.QH / p.KH));
-    int qblk = lin % p.n_qblk;
-    const int bh = lin / p.n_qblk;
-    if (kGeneral && p.causal) qblk = p.n_qblk - 1 - qblk;    // heaviest q-blocks first
+    int qblk, bh;
+    if (kPersist && p.persist > 0) {
+        const int x = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3;
+        const int pos = 32 * pstep + ((pstep & 1) ? 31 - c : c);
+        const int col = pos / p.n_qblk;
+        qblk = p.n_qblk - 1 - (pos - col * p.n_qblk);
+        bh = x * ((p.B * p.QH) >> 3) + col;
+    } else {
+        const int lin = xcd_remap_chunked(EV == E ? (int)blockIdx.x : (int)blockIdx.x % p.n_wg, p.n_wg, p.n_qblk * (p.QH / p.KH));
+        qblk = lin % p.n_qblk;
+        bh = lin / p.n_qblk;
+        if (kGeneral && p.causal) qblk = p.n_qblk - 1 - qblk;    // heaviest q-blocks first
+    }
     const int b = bh / p.QH, qh = bh - b * p.QH;
     const int kvh = qh / (p.QH / p.KH);                      // cld(q_head, n_q_per_kv), 0-based (src/attention.jl:28)
     const int q0w = qblk * 256 + wave * 64;                  // first query row of this wave
@@ -982,6 +1013,9 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p) {
         dbg[10] = stamp_p[1];
     }
 #endif
+    // the next block's prologue overwrites the rings and the validity words: every wave is done reading them
+    if (pstep + 1 < n_steps_pers) __syncthreads();
+    }   // blocks of this workgroup
 }
 
 }  // namespace nnop

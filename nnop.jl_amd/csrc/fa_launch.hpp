@@ -86,6 +86,21 @@ inline size_t bwd_workspace_bytes_pair(const nnop_fa_desc& d) {
 }
 
 
+// Compute units of the current device (cached per device ordinal < 64; 0 if the query fails)
+inline int device_cu_count() {
+    static int cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev >= 0 && dev < 64) {
+        const int c = __atomic_load_n(&cache[dev], __ATOMIC_RELAXED);
+        if (c > 0) return c;
+    }
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev >= 0 && dev < 64) __atomic_store_n(&cache[dev], v, __ATOMIC_RELAXED);
+    return v;
+}
+
 // Kernels that need more than 64 KiB of dynamic LDS must opt in once per (kernel, device).  `done` is a per-kernel
 // static bitmap (one bit per device ordinal < 64); setting the attribute twice is harmless, so a benign race between
 // host threads only costs a redundant call.

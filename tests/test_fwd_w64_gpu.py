@@ -182,3 +182,32 @@ def test_folded_scale_variant_in_every_mode(pkg, dev, tune, dt, E, QL, KL, causa
     scale is the default: N(0,1) logits are small, where the fold holds the standard tolerance"""
     tune(fwd_w64=1, fwd_exact_scale=0)
     check(pkg, make_inputs(78, 2, 4, 2, QL, KL, E, dt, dev, pad=pad, need_do=False), causal, dt)
+
+
+@pytest.mark.parametrize("dt,E", [("bf16", 64), ("f16", 128), ("bf16", 128)])
+@pytest.mark.parametrize("causal,pad,QL,KL", [(True, None, 2048, 2048), (True, "lens", 2048 - 13, 2048 - 37), (False, None, 2048, 1024 + 37),
+                                             (False, "random", 2048, 2048)])
+def test_persistent_block_list_is_bitwise_the_one_block_per_workgroup_launch(pkg, dev, tune, dt, E, causal, pad, QL, KL):
+    """The persistent form of the 64-row forward (256 workgroups walking a static, balanced block list; csrc/fa_fwd_w64.hpp,
+    knob fwd_persist) runs the same per-block code as the launch with one workgroup per block: outputs and residuals are bitwise
+    equal, every block is visited exactly once (a block missed or done twice by the list shows as a difference), also with ragged
+    lengths, key padding and GQA -- and repeated persistent launches are bitwise equal among themselves (the hand-over between two
+    blocks of a workgroup is one barrier: a ring slot overwritten too early would come and go with timing).  One slice against the oracle."""
+    d = make_inputs(77, 4, 16, 4, QL, KL, E, dt, dev, pad=pad, need_do=False)        # B x QH = 64 columns: 8 per XCD, 2 steps of 32 blocks
+    flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
+    tune(fwd_w64=1, fwd_persist=0)
+    ref = run(pkg, d, causal)
+    tune(fwd_w64=1, fwd_persist=1)
+    for _ in range(3):
+        flush.fill_(1)
+        got = run(pkg, d, causal)
+        for a, b, name in zip(ref, got, ("o", "ms", "ls")):
+            assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), name
+    from oracle.naive_attention import naive_attention_slice
+    b, kh = 3, 2
+    hs = slice(kh * 4, kh * 4 + 4)
+    f64 = lambda t: t.double().cpu().numpy()
+    o_ref = naive_attention_slice(f64(d["q"][b, hs]), f64(d["k"][b, kh]), f64(d["v"][b, kh]), None, causal=causal,
+                                  kpad_mask=None if d["mask"] is None else d["mask"][b].cpu().numpy())["o"]
+    from util import assert_close
+    assert_close("o", got[0][b, hs], o_ref, dt)

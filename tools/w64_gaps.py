@@ -41,14 +41,15 @@ def main():
         lines = [l.split(";")[0].strip() for l in body.split("\n")]
         lines = [l for l in lines if l and (not l.startswith(".") or l.endswith(":"))]
         labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
-        best = None
+        cands = []
         for i, l in enumerate(lines):
             m = re.match(r"s_c?branch\w* (\S+)", l)
             if m and m.group(1) in labels and labels[m.group(1)] < i:
                 s = labels[m.group(1)]
-                n = sum(1 for x in lines[s:i] if x.startswith("v_mfma"))
-                if best is None or n > best[2]: best = (s, i, n)
-        s, e, n = best
+                cands.append((s, i, sum(1 for x in lines[s:i] if x.startswith("v_mfma"))))
+        # the hand-placed loop = the INNERMOST region with the most MFMAs (the persistent forward wraps it in a loop over blocks)
+        inner = [c for c in cands if not any(o is not c and c[0] <= o[0] and o[1] <= c[1] and o[2] >= 16 and (o[0], o[1]) != (c[0], c[1]) for o in cands)]
+        s, e, n = max(inner or cands, key=lambda c: c[2])
         # common path: skip forward-branch regions that contain accumulator reads (the rescale blocks)
         path, i = [], s
         while i <= e:

@@ -9,6 +9,7 @@ pkg = ge.load_package()
 dev = torch.device("cuda:0")
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}
 pkg._lib.debug_set("fwd_w64", 1)
+pkg._lib.debug_set("fwd_persist", 0)          # the stamps describe ONE block per workgroup (the persistent form would overwrite them per block)
 for c in sys.argv[1:] or ["bf16:64:4096:4:4:4"]:
     f = c.split(":"); dt, (E, L, QH, KH, B) = f[0], map(int, f[1:6]); causal = len(f) > 6 and f[6] == "causal"
     q = torch.randn(B, QH, L, E, device=dev).to(DT[dt]); k = torch.randn(B, KH, L, E, device=dev).to(DT[dt]); v = torch.randn_like(k)
@@ -28,6 +29,9 @@ for c in sys.argv[1:] or ["bf16:64:4096:4:4:4"]:
     per_tile = (loop / nt).median().item()
     p1, p2 = (rows[:, 9] - t[:, 0]).median().item(), (rows[:, 10] - rows[:, 9]).median().item()
     span = (r[:, 3].max() - r[:, 0].min()).item() * 10e-3                              # us, first entry -> last exit
+    busy = (r[:, 3] - r[:, 0]).sum().item() * 10e-3 / 256                              # us of workgroup residency per CU (256 CUs, one workgroup each)
+    by_phase = [(x * 1.0).sum().item() / (t[:, 3] - t[:, 0]).sum().item() for x in (pro, loop, epi)]
+    print(f"{c}: residency per CU {busy:.1f} us of {span:.1f} us ({busy / span:.3f}); share of resident cycles: prologue {by_phase[0]:.3f} loop {by_phase[1]:.3f} epilogue {by_phase[2]:.3f}", flush=True)
     print(f"{c}: {n} launches; clock {clk:.3f} GHz; per WG median cycles: prologue {pro.median().item():.0f} (K0+Q landed {p1:.0f}, S0 +{p2:.0f})  loop {loop.median().item():.0f}"
           f"  epilogue {epi.median().item():.0f}; tiles {nt.median().item():.0f}; cycles / tile {per_tile:.0f} = {per_tile / mf:.1f} per MFMA ({mf} MFMA / tile)"
           f"; wall {wall:.1f} us / launch, first entry -> last exit {span:.1f} us; entry spread {(r[:, 0].max() - r[:, 0].min()).item() * 10e-3:.2f} us", flush=True)
