@@ -63,6 +63,7 @@ struct BwdParams {
     const void* pair_a;
     void* dpair_s;
     int   QLp, KLp;
+    int   persist = 0;   // fa_bwd_w64_kernel: blocks per workgroup of the persistent form (grid = 256 workgroups), 0 = one block per workgroup
 };
 
 // An fp32 row constant as three 16-bit terms (hi, mid, lo, 0 ...) whose sum is the value to ~24 bits: the form in which the dK/dV

@@ -75,7 +75,22 @@ static int launch_bwd_w64(const nnop_fa_desc& d, const BwdParams& p, hipStream_t
     if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     pk.n_wg = (int)n_wg;
     if (n_wg * SH::NSPLIT > 0x7fffffffLL) return NNOP_ERR_SHAPE;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg * SH::NSPLIT)), dim3(256), lds, s, pk);      // E = 256 dK/dV: every block twice (column halves)
+    // Persistent form (as the forward's, fa_fwd_inst.hpp launch_fwd_w64): 256 workgroups over a static balanced block list, under a
+    // causal mask without key padding, when the list divides.  Knob kTuneBwdPersist (0 never, 1 wherever it divides).
+    long long grid = n_wg * SH::NSPLIT;
+    pk.persist = 0;
+    if constexpr (MODE == 1 && SH::NSPLIT == 1) {
+        const long long cols = (long long)d.batch * hd;
+        const int n = pk.n_blk;
+        const long long per_xcd = (cols / 8) * n;
+        const int knob = tune_get(kTuneBwdPersist);
+        if ((knob == 1 || (knob < 0 && d.causal && !p.kpad)) && device_cu_count() == 256 && cols % 8 == 0 && (n & (n - 1)) == 0 &&
+            per_xcd % 32 == 0 && per_xcd / 32 >= 2 && per_xcd / 32 <= (1 << 24)) {
+            pk.persist = (int)(per_xcd / 32);
+            grid = 256;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, pk);      // E = 256 dK/dV: every block twice (column halves)
     return NNOP_OK;
 }
 // Is the one-wave-per-SIMD form instantiated for this problem (16-bit, E = 64 / 128, no pair bias), and do its 32-bit descriptor

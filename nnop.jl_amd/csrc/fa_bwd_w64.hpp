@@ -250,7 +250,7 @@ template <typename T, int EB> NNOP_DEV void store_acc_row16(T* rowp, f32x16 (&ac
 }
 
 template <typename T, int E, int KIND, int MODE>
-__global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
+__global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_arg) {
     using SH = BwdW64Shape<E, KIND>;
     using frag_t = typename Elem<T>::frag;
     using Img = DualImg<T, E>;
@@ -268,11 +268,45 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
     stamp[0] = __builtin_amdgcn_s_memtime();
     stamp[1] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+
+    // ---- persistent form (p.persist = blocks per workgroup, masked-mode kernels; fa_fwd_w64.hpp has the reasoning and the list):
+    // 256 workgroups, XCD x owns the (batch, head) columns [x C/8, (x+1) C/8), its blocks -- heaviest first inside a column: the last
+    // query block for dQ, the first key block for dK/dV under the causal mask -- dealt out 32 at a time, alternately forwards and
+    // backwards over the XCD's workgroups.  The parameters are re-read from the kernel-argument segment per block.
+    constexpr bool kPersist = kGeneral && SH::NSPLIT == 1;
+    const int n_steps_pers = (kPersist && p_arg.persist > 0) ? p_arg.persist : 1;
+    for (int pstep = 0; pstep < n_steps_pers; ++pstep) {
+    // lane indices are re-derived per block from a value the compiler cannot hoist: kept live across the register-full hand-placed
+    // loop of the previous block they were spilled to scratch around it (E = 128)
+    int lane0 = 0;
+    if constexpr (kPersist) asm volatile("s_mov_b32 %0, 0" : "=s"(lane0));
+    const int lane = kPersist ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (uint32_t)lane0)) : ((int)threadIdx.x & 63);
+    const int tid = wave * 64 + lane;
     const int r = lane & 31, h = lane >> 5;
+    BwdParams p_blk;
+    if constexpr (!kPersist) p_blk = p_arg;
+    if constexpr (kPersist) {
+        p_blk.dpair = nullptr; p_blk.pair = nullptr; p_blk.pair_a = nullptr; p_blk.dpair_s = nullptr; p_blk.QLp = 0; p_blk.KLp = 0;
+        typedef const BwdParams __attribute__((address_space(4))) * params_cp;
+        params_cp pp = (params_cp)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pp));
+        p_blk.dq = pp->dq; p_blk.dk = pp->dk; p_blk.dv = pp->dv; p_blk.d_o = pp->d_o; p_blk.o = pp->o; p_blk.ms = pp->ms; p_blk.ls = pp->ls;
+        p_blk.q = pp->q; p_blk.k = pp->k; p_blk.v = pp->v; p_blk.kpad = pp->kpad; p_blk.nl = pp->nl; p_blk.delta = pp->delta;
+        p_blk.QL = pp->QL; p_blk.KL = pp->KL; p_blk.QH = pp->QH; p_blk.KH = pp->KH; p_blk.B = pp->B; p_blk.causal = pp->causal;
+        p_blk.QLs = pp->QLs; p_blk.fused = pp->fused; p_blk.rcf = pp->rcf; p_blk.n_blk = pp->n_blk; p_blk.n_wg = pp->n_wg;
+        p_blk.scale = pp->scale; p_blk.persist = pp->persist;
+    }
+    const BwdParams& p = p_blk;
     const float c2 = p.scale * kLog2e;
     const int rep = p.QH / p.KH;
+    int pers_col = 0, pers_k = 0;      // persistent form: column inside the XCD's share, rank of the block inside the column (0 = heaviest)
+    if (kPersist && p.persist > 0) {
+        const int c = (int)blockIdx.x >> 3;
+        const int pos = 32 * pstep + ((pstep & 1) ? 31 - c : c);
+        pers_col = pos / p.n_blk;
+        pers_k = pos - pers_col * p.n_blk;
+    }
 
     // ---- which block; the stationary rows of this wave; the streamed sequence ------------------------------------------------
     int b, kvh, bh_s;                  // bh_s: (batch, head) index of the stationary tensors
@@ -280,10 +314,16 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
     int SL, TL;                        // stationary / streamed sequence lengths
     int heads, u0 = 0, nps;            // streamed heads (dK/dV under GQA), first step, steps per head
     if constexpr (kDQ) {
-        const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk * rep);
-        int blk = lin % p.n_blk;
-        bh_s = lin / p.n_blk;
-        if (kGeneral && p.causal) blk = p.n_blk - 1 - blk;                 // heaviest query blocks first
+        int blk;
+        if (kPersist && p.persist > 0) {
+            blk = p.n_blk - 1 - pers_k;
+            bh_s = ((int)blockIdx.x & 7) * ((p.B * p.QH) >> 3) + pers_col;
+        } else {
+            const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk * rep);
+            blk = lin % p.n_blk;
+            bh_s = lin / p.n_blk;
+            if (kGeneral && p.causal) blk = p.n_blk - 1 - blk;             // heaviest query blocks first
+        }
         b = bh_s / p.QH;
         kvh = (bh_s - b * p.QH) / rep;
         s0wg = blk * SH::WG_ROWS;
@@ -297,9 +337,15 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         }
     } else {
         // (E = 256: the grid holds every workgroup NSPLIT times; copy `esplit` accumulates the column blocks esplit * EB ..)
-        const int lin = xcd_remap_chunked((int)blockIdx.x % p.n_wg, p.n_wg, p.n_blk);
-        const int blk = lin % p.n_blk;
-        bh_s = lin / p.n_blk;
+        int blk;
+        if (kPersist && p.persist > 0) {
+            blk = pers_k;                                                  // causal: the first key block sees every query
+            bh_s = ((int)blockIdx.x & 7) * ((p.B * p.KH) >> 3) + pers_col;
+        } else {
+            const int lin = xcd_remap_chunked((int)blockIdx.x % p.n_wg, p.n_wg, p.n_blk);
+            blk = lin % p.n_blk;
+            bh_s = lin / p.n_blk;
+        }
         b = bh_s / p.KH;
         kvh = bh_s - b * p.KH;
         s0wg = blk * SH::WG_ROWS;
@@ -1007,6 +1053,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p) {
         dbg[6] = (uint64_t)n_steps;
     }
 #endif
+    // the next block's prologue overwrites the ring, the V image and the flag / validity words: every wave is done reading them
+    if (pstep + 1 < n_steps_pers) __syncthreads();
+    }   // blocks of this workgroup
 }
 
 }  // namespace nnop

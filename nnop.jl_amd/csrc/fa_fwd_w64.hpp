@@ -339,8 +339,10 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p_ar
     typedef const FwdParams __attribute__((address_space(4))) * params_cp;
     params_cp pp = (params_cp)__builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (kPersist) asm volatile("" : "+s"(pp));
-    FwdParams p_blk = p_arg;
+    FwdParams p_blk;
+    if constexpr (!kPersist) p_blk = p_arg;
     if constexpr (kPersist) {
+        p_blk.pair = nullptr;
         p_blk.o = pp->o; p_blk.ms = pp->ms; p_blk.ls = pp->ls; p_blk.q = pp->q; p_blk.k = pp->k; p_blk.v = pp->v; p_blk.kpad = pp->kpad;
         p_blk.QL = pp->QL; p_blk.KL = pp->KL; p_blk.QH = pp->QH; p_blk.KH = pp->KH; p_blk.B = pp->B; p_blk.causal = pp->causal;
         p_blk.n_qblk = pp->n_qblk; p_blk.n_wg = pp->n_wg; p_blk.scale = pp->scale; p_blk.persist = pp->persist;

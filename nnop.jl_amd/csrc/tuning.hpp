@@ -23,6 +23,7 @@ enum TuneKey {
     kTuneBwdW64,         // NNOP_BWD_W64     one-wave-per-SIMD backward (fa_bwd_w64.hpp): 0 never, 1 both passes, 2 dK/dV only, 3 dQ only, 4 both + separate preprocess launch
     kTuneBwdStages,      // (no environment variable; nnop_debug_set only)  measurement only: which passes of the tiled backward run (bit mask: 1 preprocess, 2 dK/dV, 4 dQ)
     kTuneFwdPersist,     // NNOP_FWD_PERSIST 64-row forward as 256 persistent workgroups that walk a static block list: 0 never, 1 / auto wherever the list balances
+    kTuneBwdPersist,     // NNOP_BWD_PERSIST the same for the one-wave-per-SIMD backward kernels
     kTuneCount
 };
 

@@ -187,3 +187,31 @@ def test_misaligned_workspace_takes_the_fallback(pkg, dev, tune, E):
         assert_close("dq", dq, rq, "bf16", kind="grad")
         assert_close("dk", dk, rk, "bf16", kind="grad")
         assert_close("dv", dv, rv, "bf16", kind="grad")
+
+
+@pytest.mark.parametrize("dt,E,QH,KH,L", [("bf16", 64, 16, 16, 2048), ("f16", 128, 16, 16, 2048), ("bf16", 128, 16, 8, 4096)])
+@pytest.mark.parametrize("causal,pad,ragged", [(True, None, 0), (True, "lens", 13), (False, None, 37)])
+def test_persistent_block_list_is_bitwise_the_one_block_per_workgroup_launch(pkg, dev, tune, dt, E, QH, KH, L, causal, pad, ragged):
+    """The persistent form of the backward kernels (256 workgroups walking a static balanced block list, csrc/fa_bwd_w64.hpp, knob
+    bwd_persist) runs the same per-block code as the launch with one workgroup per block: dq, dk, dv are bitwise equal -- every
+    block visited exactly once, for both passes (dQ: columns = batch x q-head; dK/dV: batch x kv-head, the q-heads of a group
+    streamed inside a block) -- with ragged lengths and key padding; repeated launches bitwise equal (the hand-over between two
+    blocks is one barrier: the ring, the V image and the validity words are rewritten behind it)."""
+    B = 4
+    d = make_inputs(79, B, QH, KH, L - ragged, L - (2 * ragged if ragged else 0), E, dt, dev, pad=pad)
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], None, causal=causal, kpad_mask=d["mask"])
+    flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
+
+    def bwd():
+        g = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], None, causal=causal, kpad_mask=d["mask"])
+        torch.cuda.synchronize()
+        return g[:3]
+
+    tune(bwd_w64=1, bwd_persist=0)
+    ref = bwd()
+    tune(bwd_w64=1, bwd_persist=1)
+    for _ in range(3):
+        flush.fill_(1)
+        got = bwd()
+        for a, b_, name in zip(ref, got, ("dq", "dk", "dv")):
+            assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b_.float())), name

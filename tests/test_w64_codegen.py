@@ -52,3 +52,24 @@ def test_schedule_of_the_generated_loop_stays_balanced():
     lim = {(64, 0): 45.0, (64, 1): 49.5, (128, 0): 40.0, (128, 1): 39.5, (256, 0): 45.0, (256, 1): 44.0}        # (E, kind: 0 dK/dV, 1 dQ), plain mode
     assert set(got) == set(lim), r.stdout
     assert all(got[k] <= lim[k] for k in lim), got
+
+
+def test_scratch_only_where_it_is_known_and_never_in_the_e256_kernels():
+    """Register budget of the one-wave-per-SIMD kernels: no scratch anywhere (16-bit E = 256 in particular: spill-free on both
+    passes), except the persistent masked backward kernels of E = 128, which park a few prologue values (early-requested fragment
+    loads) around -- never inside, tools/audit_w64.py rule 1 -- the hand-placed loop, once per block."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from audit_w64 import compile_asm, kernels
+    seen = 0
+    for src, pat in (("fa_fwd_bf16.hip", "fa_fwd_w64_kernel"), ("fa_bwd_bf16.hip", "fa_bwd_w64_kernel")):
+        for name, body, meta in kernels(compile_asm(src, []), pat):
+            scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1))
+            spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
+            parked = "fa_bwd_w64_kernel" in name and "Li128E" in name and name.endswith("ELi1EEEvNS_9BwdParamsE")      # E = 128, masked mode
+            if parked:
+                assert scratch <= 128 and spills <= 32, (name, scratch, spills)
+            else:
+                assert scratch == 0 and spills == 0, (name, scratch, spills)
+            seen += 1
+    assert seen == 10 + 12

@@ -7,7 +7,7 @@ that produced it -- which then reads the accumulator registers the MFMA's last p
 stale registers 13..15 of one O tile, profiles/r02/NOTES.md).  The source keeps such copies away from MFMAs (fences at the three
 places where O is read, a fence at the end of a wave's last iteration); this script checks the RESULT, per kernel:
 
-  1. no scratch, no VGPR / SGPR spills;
+  1. no spill code (scratch, v_writelane / v_readlane) inside the hand-placed loop, at most MAX_PROLOGUE_SCRATCH bytes per lane around it;
   2. every compiler-generated read of an accumulator register (v_accvgpr_read_b32, v_accvgpr_mov_b32 source) that an MFMA wrote is
      separated from the closest preceding MFMA writing that register by a fence (>= 4 x `s_nop 15`) or by >= MIN_GAP instructions;
   3. the same for v_mov_b32 / VALU reads of VGPR tuples written by an MFMA is left to the slot schedule (checked: no v_mov_b32 from
@@ -22,6 +22,7 @@ import subprocess
 import sys
 import tempfile
 
+MAX_PROLOGUE_SCRATCH = 128          # bytes per lane a kernel may park around (never inside) its hand-placed loop
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nnop.jl_amd", "csrc")
 
@@ -82,12 +83,28 @@ def audit(name, body, meta):
     the MFMA result in it has landed (and the cycles until the matrix pipe is free); at a label the states of all incoming
     edges merge to the worst case.  Two passes so that loop back-edges reach their header."""
     errs = []
+    lines = [l.split(";")[0].strip() for l in body.split("\n")]
+    lines = [l for l in lines if l and not (l.startswith(".") and not l.endswith(":"))]
+    # 1. spills: none inside the hand-placed loop (= the innermost backward-branch region with the most MFMAs); the persistent
+    # kernels of E = 128 park a few prologue values (early-requested fragments) in scratch AROUND that loop, once per block
+    spilled = {}
     for key in (".private_segment_fixed_size", ".vgpr_spill_count", ".sgpr_spill_count"):
         m = re.search(re.escape(key) + r":\s+(\d+)", meta)
         if m and int(m.group(1)) != 0:
-            errs.append(f"{key} = {m.group(1)}")
-    lines = [l.split(";")[0].strip() for l in body.split("\n")]
-    lines = [l for l in lines if l and not (l.startswith(".") and not l.endswith(":"))]
+            spilled[key] = int(m.group(1))
+    if spilled:
+        labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
+        cands = []
+        for i, l in enumerate(lines):
+            m = re.match(r"s_c?branch\w* (\S+)", l)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                s0 = labels[m.group(1)]
+                cands.append((s0, i, sum(1 for x in lines[s0:i] if x.startswith("v_mfma"))))
+        inner = [c for c in cands if not any((o[0], o[1]) != (c[0], c[1]) and c[0] <= o[0] and o[1] <= c[1] and o[2] >= 16 for o in cands)]
+        hot = max(inner or cands or [(0, len(lines), 0)], key=lambda c: c[2])
+        in_loop = [l for l in lines[hot[0]:hot[1] + 1] if l.startswith(("scratch_", "v_writelane", "v_readlane"))]
+        if in_loop or spilled.get(".private_segment_fixed_size", 0) > MAX_PROLOGUE_SCRATCH:
+            errs += [f"{k} = {v}" for k, v in spilled.items()] + [f"spill code inside the hand-placed loop: {l}" for l in in_loop[:8]]
     edge = {}                                    # label -> merged state carried by branches to it
 
     def merge(a, b):

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 pkg = ge.load_package()
+pkg._lib.debug_set("bwd_persist", 0)          # the stamps describe ONE block per workgroup
 dev = torch.device("cuda:0")
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}
 for c in sys.argv[1:] or ["bf16:64:4096:4:4:4"]:
@@ -35,6 +36,9 @@ for c in sys.argv[1:] or ["bf16:64:4096:4:4:4"]:
         live = ns > 0
         per_it = (loop[live] / (ns[live] + 1)).median().item()
         span = (rr[:, 2].max() - rr[:, 0].min()).item() * 10e-3
+        busy = (rr[:, 2] - rr[:, 0]).sum().item() * 10e-3 / 256
+        span_all = (rr[:, 2].max() - rr[:, 0].min()).item() * 10e-3
+        print(f"{c} {kind}: residency per CU (entry -> loop exit, epilogue not included) {busy:.1f} us of {span_all:.1f} us ({busy / span_all:.3f}); {rows.shape[0]} workgroups", flush=True)
         print(f"{c} {kind}: clock {clk:.3f} GHz; per WG median cycles: prologue {pro.median().item():.0f}  loop {loop.median().item():.0f} (max {loop.max().item():.0f}); steps {ns.median().item():.0f};"
               f" cycles / iteration {per_it:.0f} = {per_it / mf:.1f} per MFMA ({mf} MFMA / iteration); first entry -> last loop exit {span:.1f} us; "
               f"entry spread {(rr[:, 0].max() - rr[:, 0].min()).item() * 10e-3:.2f} us", flush=True)
