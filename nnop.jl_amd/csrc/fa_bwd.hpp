@@ -63,6 +63,7 @@ struct BwdParams {
     const void* pair_a;
     void* dpair_s;
     int   QLp, KLp;
+    int   persist_hx = 0;   // persistent form: heads of the column axis per XCD when they divide by 8 (fa_fwd.hpp), else 0
     int   persist = 0;   // fa_bwd_w64_kernel: blocks per workgroup of the persistent form (grid = 256 workgroups), 0 = one block per workgroup
 };
 

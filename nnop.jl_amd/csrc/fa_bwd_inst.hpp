@@ -84,9 +84,14 @@ static int launch_bwd_w64(const nnop_fa_desc& d, const BwdParams& p, hipStream_t
         const int n = pk.n_blk;
         const long long per_xcd = (cols / 8) * n;
         const int knob = tune_get(kTuneBwdPersist);
-        if ((knob == 1 || (knob < 0 && d.causal && !p.kpad)) && device_cu_count() == 256 && cols % 8 == 0 && (n & (n - 1)) == 0 &&
+        const int hx = hd % 8 == 0 ? hd / 8 : 0;
+        // (key padding without a causal mask: the dQ pass only -- every query block of a batch costs the same there, while the key
+        // blocks of the dK/dV pass are full or EMPTY by the batch's length and a static list cannot pair them up: measured -17 % at C4)
+        const bool pays = (d.causal && !p.kpad) || (KIND == kBwdDQ && !d.causal && p.kpad && hx > 0);
+        if ((knob == 1 || (knob < 0 && pays)) && device_cu_count() == 256 && cols % 8 == 0 && (n & (n - 1)) == 0 &&
             per_xcd % 32 == 0 && per_xcd / 32 >= 2 && per_xcd / 32 <= (1 << 24)) {
             pk.persist = (int)(per_xcd / 32);
+            pk.persist_hx = hx;
             grid = 256;
         }
     }

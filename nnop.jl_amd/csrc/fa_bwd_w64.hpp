@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_ar
         p_blk.q = pp->q; p_blk.k = pp->k; p_blk.v = pp->v; p_blk.kpad = pp->kpad; p_blk.nl = pp->nl; p_blk.delta = pp->delta;
         p_blk.QL = pp->QL; p_blk.KL = pp->KL; p_blk.QH = pp->QH; p_blk.KH = pp->KH; p_blk.B = pp->B; p_blk.causal = pp->causal;
         p_blk.QLs = pp->QLs; p_blk.fused = pp->fused; p_blk.rcf = pp->rcf; p_blk.n_blk = pp->n_blk; p_blk.n_wg = pp->n_wg;
-        p_blk.scale = pp->scale; p_blk.persist = pp->persist;
+        p_blk.scale = pp->scale; p_blk.persist = pp->persist; p_blk.persist_hx = pp->persist_hx;
     }
     const BwdParams& p = p_blk;
     const float c2 = p.scale * kLog2e;
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_ar
         int blk;
         if (kPersist && p.persist > 0) {
             blk = p.n_blk - 1 - pers_k;
-            bh_s = ((int)blockIdx.x & 7) * ((p.B * p.QH) >> 3) + pers_col;
+            if (p.persist_hx > 0) bh_s = (pers_col / p.persist_hx) * p.QH + ((int)blockIdx.x & 7) * p.persist_hx + pers_col % p.persist_hx;
+            else bh_s = ((int)blockIdx.x & 7) * ((p.B * p.QH) >> 3) + pers_col;
         } else {
             const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk * rep);
             blk = lin % p.n_blk;
@@ -340,7 +341,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_ar
         int blk;
         if (kPersist && p.persist > 0) {
             blk = pers_k;                                                  // causal: the first key block sees every query
-            bh_s = ((int)blockIdx.x & 7) * ((p.B * p.KH) >> 3) + pers_col;
+            if (p.persist_hx > 0) bh_s = (pers_col / p.persist_hx) * p.KH + ((int)blockIdx.x & 7) * p.persist_hx + pers_col % p.persist_hx;
+            else bh_s = ((int)blockIdx.x & 7) * ((p.B * p.KH) >> 3) + pers_col;
         } else {
             const int lin = xcd_remap_chunked((int)blockIdx.x % p.n_wg, p.n_wg, p.n_blk);
             blk = lin % p.n_blk;

@@ -87,6 +87,7 @@ struct FwdParams {
     int   n_qblk;            // ceil(QL / (32*QB*NW))
     int   n_wg;              // n_qblk * QH * B
     float scale;             // 1/sqrt(E)
+    int   persist_hx = 0;    // persistent form: heads per XCD when QH % 8 == 0 (the XCD's columns = those heads of every batch), else 0
     int   persist = 0;       // fa_fwd_w64_kernel: blocks per workgroup of the persistent form (grid = 256 workgroups), 0 = one block per workgroup
 #ifdef NNOP_DEV_BUILD
     int   stagger = 0;       // experiment: s_sleep units for the odd co-resident workgroup (0 = off)

@@ -117,9 +117,13 @@ static int launch_fwd_w64(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
         // L 8192-16384, +23 % at E = 64 L4096 H16 B4; equal-work blocks gain nothing (+-0.3 %), and per-batch key lengths make a
         // static list 15 % SLOWER than the dispatcher's dynamic order: C4)
         const int knob = tune_get(kTuneFwdPersist);
-        if ((knob == 1 || (knob < 0 && d.causal && !a.kpad)) && device_cu_count() == 256 && bh % 8 == 0 && (n & (n - 1)) == 0 &&
+        // per-batch key lengths WITHOUT a causal mask: balanced as well once every XCD takes an eighth of the heads of every batch
+        const int hx = d.qh % 8 == 0 ? d.qh / 8 : 0;
+        const bool pays = (d.causal && !a.kpad) || (!d.causal && a.kpad && hx > 0);
+        if ((knob == 1 || (knob < 0 && pays)) && device_cu_count() == 256 && bh % 8 == 0 && (n & (n - 1)) == 0 &&
             per_xcd % 32 == 0 && per_xcd / 32 >= 2 && per_xcd / 32 <= (1 << 24)) {
             p.persist = (int)(per_xcd / 32);
+            p.persist_hx = hx;
             grid = 256;
         }
     }

@@ -184,9 +184,9 @@ def test_folded_scale_variant_in_every_mode(pkg, dev, tune, dt, E, QL, KL, causa
     check(pkg, make_inputs(78, 2, 4, 2, QL, KL, E, dt, dev, pad=pad, need_do=False), causal, dt)
 
 
-@pytest.mark.parametrize("dt,E", [("bf16", 64), ("f16", 128), ("bf16", 128)])
-@pytest.mark.parametrize("causal,pad,QL,KL", [(True, None, 2048, 2048), (True, "lens", 2048 - 13, 2048 - 37), (False, None, 2048, 1024 + 37),
-                                             (False, "random", 2048, 2048)])
+@pytest.mark.parametrize("dt,E,causal,pad,QL,KL", [
+    ("bf16", 64, True, None, 2048, 2048), ("bf16", 64, False, "random", 2048, 2048), ("f16", 128, True, "lens", 2048 - 13, 2048 - 37),
+    ("f16", 128, False, None, 2048, 1024 + 37), ("bf16", 128, True, None, 2048, 2048), ("bf16", 128, False, "lens", 2048, 2048)])
 def test_persistent_block_list_is_bitwise_the_one_block_per_workgroup_launch(pkg, dev, tune, dt, E, causal, pad, QL, KL):
     """The persistent form of the 64-row forward (256 workgroups walking a static, balanced block list; csrc/fa_fwd_w64.hpp,
     knob fwd_persist) runs the same per-block code as the launch with one workgroup per block: outputs and residuals are bitwise
