@@ -191,7 +191,8 @@ def test_misaligned_workspace_takes_the_fallback(pkg, dev, tune, E):
 
 @pytest.mark.parametrize("dt,E,QH,KH,L,causal,pad,ragged", [
     ("bf16", 64, 16, 16, 2048, True, None, 0), ("bf16", 64, 16, 16, 2048, False, "lens", 0), ("f16", 128, 16, 16, 2048, True, "lens", 13),
-    ("f16", 128, 16, 16, 2048, False, None, 37), ("bf16", 128, 16, 8, 4096, True, None, 0)])
+    ("f16", 128, 16, 16, 2048, False, None, 37), ("bf16", 128, 16, 8, 4096, True, None, 0),
+    ("bf16", 256, 16, 16, 2048, True, "lens", 0)])         # E = 256: the dQ pass only (its dK/dV pass runs every block twice, column halves)
 def test_persistent_block_list_is_bitwise_the_one_block_per_workgroup_launch(pkg, dev, tune, dt, E, QH, KH, L, causal, pad, ragged):
     """The persistent form of the backward kernels (256 workgroups walking a static balanced block list, csrc/fa_bwd_w64.hpp, knob
     bwd_persist) runs the same per-block code as the launch with one workgroup per block: dq, dk, dv are bitwise equal -- every
