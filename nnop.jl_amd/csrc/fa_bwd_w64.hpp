@@ -1023,12 +1023,20 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_ar
 
     // ---- epilogue: store the gradient rows of this wave's stationary rows ---------------------------------------------------------
     fence_acc_result(acc[0][0][0]);                         // the one fence of the epilogue (fa_fwd_w64.hpp, "RULE")
+    // (persistent form: the lane's row indices are derived AGAIN here -- kept live across the register-full loop they are what hipcc
+    // spills around it)
+    int lane1 = 0;
+    if constexpr (kPersist) asm volatile("s_mov_b32 %0, 0" : "=s"(lane1));
+    const int lane_e = kPersist ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (uint32_t)lane1)) : lane;
+    const int h_e = lane_e >> 5;
 #pragma unroll
     for (int zs = 0; zs < ZS; ++zs) {
-        const bool in = sidx[zs] < SL;
+        const int sidx_e = kPersist ? s0w + 32 * zs + (lane_e & 31) : sidx[zs];
+        const int sidx_ce = sidx_e < SL ? sidx_e : SL - 1;
+        const bool in = sidx_e < SL;
         if constexpr (kDQ) {
-            T* row = (T*)p.dq + ((size_t)bh_s * p.QL + sidx_c[zs]) * E + esplit * EB * 32;
-            store_acc_row16<T, EB>(row, acc[0][zs], p.scale, h, in);
+            T* row = (T*)p.dq + ((size_t)bh_s * p.QL + sidx_ce) * E + esplit * EB * 32;
+            store_acc_row16<T, EB>(row, acc[0][zs], p.scale, h_e, in);
         } else {
             if constexpr (kGeneral) {
                 if (!svalid[zs]) {                           // padded-out key: its lane accumulated garbage (key on the lane)
@@ -1042,9 +1050,9 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_ar
                         }
                 }
             }
-            const size_t ro = ((size_t)bh_s * p.KL + sidx_c[zs]) * E + esplit * EB * 32;
-            store_acc_row16<T, EB>((T*)p.dv + ro, acc[0][zs], 1.0f, h, in);
-            store_acc_row16<T, EB>((T*)p.dk + ro, acc[1][zs], p.scale, h, in);
+            const size_t ro = ((size_t)bh_s * p.KL + sidx_ce) * E + esplit * EB * 32;
+            store_acc_row16<T, EB>((T*)p.dv + ro, acc[0][zs], 1.0f, h_e, in);
+            store_acc_row16<T, EB>((T*)p.dk + ro, acc[1][zs], p.scale, h_e, in);
         }
     }
 #if NNOP_BW64_STAMP

@@ -56,7 +56,7 @@ def test_schedule_of_the_generated_loop_stays_balanced():
 
 def test_scratch_only_where_it_is_known_and_never_in_the_e256_kernels():
     """Register budget of the one-wave-per-SIMD kernels: no scratch anywhere (16-bit E = 256 in particular: spill-free on both
-    passes), except the persistent masked backward kernels of E = 128, which park a few prologue values (early-requested fragment
+    passes), except the persistent masked dQ kernel of E = 128, which parks a few prologue values (early-requested fragment
     loads) around -- never inside, tools/audit_w64.py rule 1 -- the hand-placed loop, once per block."""
     import re
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -66,9 +66,9 @@ def test_scratch_only_where_it_is_known_and_never_in_the_e256_kernels():
         for name, body, meta in kernels(compile_asm(src, []), pat):
             scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1))
             spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
-            parked = "fa_bwd_w64_kernel" in name and "Li128E" in name and name.endswith("ELi1EEEvNS_9BwdParamsE")      # E = 128, masked mode
+            parked = "fa_bwd_w64_kernelIDF16bLi128ELi1ELi1E" in name                                           # E = 128, dQ pass, masked mode
             if parked:
-                assert scratch <= 128 and spills <= 32, (name, scratch, spills)
+                assert scratch <= 128 and spills <= 24, (name, scratch, spills)
             else:
                 assert scratch == 0 and spills == 0, (name, scratch, spills)
             seen += 1
