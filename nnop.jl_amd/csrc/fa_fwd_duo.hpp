@@ -1,0 +1,378 @@
+// fa_fwd_duo.hpp -- forward kernel, "two waves per SIMD in alternating phases" form (16-bit types, E = 64).
+//
+// What `_flash_attention_fwd!` computes (src/attention.jl:1-131; its hot loop :49-121), fourth program form.  Why it exists: at
+// E = 64 one 32x32x16 MFMA covers only two score elements per lane, and each element costs one v_exp_f32 (8 cycles of the SIMD's
+// vector port) plus ~3 plain VALU instructions (4 each for a single wave) -- a wave that owns its SIMD alone (fa_fwd_w64.hpp)
+// issues 2067 cycles of instructions per 64 x 64 tile against 1280 cycles of matrix-pipe work, i.e. the WAVE, not the pipe, is the
+// bound.  Two waves on a SIMD issue into the vector port independently, and one wave's VALU work runs beside the other's MFMAs
+// (tools/ubench/pingpong.hip, profiles/r04/pingpong.log: the same instruction mix runs 2461 cycles per tile serially in one wave,
+// 1482 as two waves in opposite phases).
+//
+//   * workgroup = 8 waves = 256 query rows of one (batch, q-head).  Waves w and w + 4 (SIMD partners: a workgroup's waves go to the
+//     SIMDs cyclically) own the SAME 64 query rows and split the KEYS: group 0 (waves 0-3) takes the even kv tiles, group 1 the odd
+//     ones, each with its own online-softmax state (reference, sum, O); the two partial results are merged once, through LDS, in
+//     the epilogue (each partner finishes and stores 32 of the 64 rows).  64 rows per wave keep what the one-wave form has: every K /
+//     V fragment read from LDS feeds two MFMAs (z = 0, 1).
+//   * a wave alternates a MATRIX phase M(t) -- row sums of P(t-2) (ones x P^T, 8 MFMAs), S(t) = K(t) Q^T (16), O += V(t-2)^T P(t-2)^T
+//     (16), with the LDS fragment reads and its share of the LDS-DMA of K(t+2) and V(t) in the gaps -- and a VECTOR phase V(t): mask,
+//     row max, (rare) rescale, P = exp2(s c - m), convert.  One s_barrier closes every phase; group 1 runs one phase behind group 0,
+//     so at any time each SIMD holds one wave in its matrix phase and one in its vector phase.  Nothing is software-pipelined INSIDE
+//     a wave (one score tile, 256 registers per wave); the hardware overlaps the partners.
+//   * registers (256 per wave, all arch VGPRs): O^T (64), Q fragments (32), row-sum accumulators (8), one score tile (64) whose
+//     registers also take the packed P^T words, a fragment ring (16).  That leaves hipcc's allocator no slack (given virtual
+//     16-register tuples it moved whole tiles between phases and spilled the Q fragments: 228-312 bytes of scratch per lane in every
+//     variant tried), so every tile has a HOME register and the phases are instruction streams generated with those registers
+//     (tools/gen_duo_asm.py -> fa_fwd_duo_asm.inc); C++ hands the tiles to each statement with the matching physical-register
+//     constraint and allocates only the remaining ~64 registers.  hipcc pads nothing around asm: the streams carry their own
+//     s_waitcnt lgkmcnt and wait states (same hazards as fa_fwd_w64.hpp).
+//   * K / V rings of 3 tiles each, filled by LDS-DMA (the group that reads a tile also copies it): K(t+2) and V(t) are issued in
+//     M(t), waited for at the end of V(t) (a whole phase later), published by the barrier behind it and read in M(t+2).
+//
+// Modes: 0 plain / 1 masked (causal, key padding, ragged KL).  Exact fp32 scale only.  Same numerics contract as the other forms
+// (fp32 softmax, deferred row max with threshold 2^8, O normalised once, residuals ms / ls per src/attention.jl:128-129); the
+// summation order over keys differs from the one-wave form (two partial sums per row), so results agree to rounding, not bitwise.
+#pragma once
+#include "fa_fwd_w64.hpp"
+#include "fa_fwd_duo_asm.inc"
+
+#if !defined(NNOP_DEV_BUILD)
+#undef NNOP_DUO_STAMP
+#undef NNOP_DUO_PRIO
+#endif
+#ifndef NNOP_DUO_STAMP
+#define NNOP_DUO_STAMP 0
+#endif
+#ifndef NNOP_DUO_PRIO
+#define NNOP_DUO_PRIO 0
+#endif
+
+namespace nnop {
+
+// Operands of the generated loop statement: every tile in its home register (register map: tools/gen_duo_asm.py)
+#define NNOP_DUO_OPERANDS                                                                                                        \
+    "+{v[0:15]}"(oacc[0][0]), "+{v[16:31]}"(oacc[0][1]), "+{v[32:47]}"(oacc[1][0]), "+{v[48:63]}"(oacc[1][1]), "+{v[64:79]}"(qf[0]),   \
+        "+{v[80:95]}"(qf[1]), "+{v[96:99]}"(lacc[0]), "+{v[100:103]}"(lacc[1]), "+{v[104:107]}"(sel), "+{v[112:127]}"(sc[0][0]),      \
+        "+{v[128:143]}"(sc[0][1]), "+{v[144:159]}"(sc[1][0]), "+{v[160:175]}"(sc[1][1]), "+{v[192:195]}"(mstate)                         \
+        : "{v[196:203]}"(vconst), "{v[224:239]}"(sstate), "{v[240:243]}"(krs), "{v[244:247]}"(vrs)                                 \
+        : "memory", "vcc", "scc", "v108", "v109", "v110", "v111", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", \
+          "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212",   \
+          "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "s56", "s57", "s58", "s59", "s60", "s61",  \
+          "s62", "s63", "s64", "s65", "s66", "s67", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", \
+          "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55"
+
+constexpr int kDuoXchgBytes = 8 * (8192 + 3 * 256);          // epilogue exchange: per wave 32 fp32 per lane + (l, m2, mt)
+template <typename T, int E> constexpr int fa_fwd_duo_lds_bytes(bool masked) {
+    constexpr int ring = 3 * (RowImg<T, E>::bytes(64) + ColImg<T, E>::bytes(64));
+    return (ring > kDuoXchgBytes ? ring : kDuoXchgBytes) + (masked ? 16 + 8 * kMaxMaskTiles : 0);
+}
+
+template <typename T, int E, int MODE>
+__global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
+    static_assert(sizeof(T) == 2 && E == 64, "16-bit element types, E = 64");
+    using frag_t = typename Elem<T>::frag;
+    using KImg   = RowImg<T, E>;
+    using VImg   = ColImg<T, E>;
+    using MM     = MfmaAsm<T>;
+    constexpr bool kGeneral = MODE != 0;
+    constexpr int BK = 64, KB = 2, KS = E / 16, EB = E / 32, NS = 3;
+    constexpr int KBYTES = KImg::bytes(BK), VBYTES = VImg::bytes(BK);
+    constexpr int RING = NS * (KBYTES + VBYTES);
+    constexpr int MASK_OFF = RING > kDuoXchgBytes ? RING : kDuoXchgBytes;
+    constexpr int TILE_BYTES = BK * E * (int)sizeof(T);
+    constexpr int NJK = KBYTES / 4096, NJV = VBYTES / 4096;   // DMA pieces per wave and tile (the 4 waves of a group copy a tile)
+    static_assert(NJK * 4096 == KBYTES && NJV * 4096 == VBYTES && NJK <= 4 && NJV <= 4, "four waves x NJ pieces = one image");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#if NNOP_DUO_STAMP
+    uint64_t stamp[8];
+    stamp[0] = __builtin_amdgcn_s_memtime();
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;                 // key group (tile parity) / 64-row slice of the block
+    const int r = lane & 31, h = lane >> 5;
+
+    const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_qblk * (p.QH / p.KH));
+    int qblk = lin % p.n_qblk;
+    const int bh = lin / p.n_qblk;
+    if (kGeneral && p.causal) qblk = p.n_qblk - 1 - qblk;     // heaviest q-blocks first
+    const int b = bh / p.QH, qh = bh - b * p.QH;
+    const int kvh = qh / (p.QH / p.KH);                       // cld(q_head, n_q_per_kv), 0-based (src/attention.jl:28)
+    const int q0w = qblk * 256 + wq * 64;                     // first query row of this wave (and of its partner)
+    int qi[2];
+    qi[0] = q0w + r;
+    qi[1] = q0w + 32 + r;
+
+    const T* __restrict__ qp = (const T*)p.q + ((size_t)bh * p.QL) * E;
+    const char* __restrict__ kp = (const char*)((const T*)p.k + ((size_t)(b * p.KH + kvh) * p.KL) * E);
+    const char* __restrict__ vp = (const char*)((const T*)p.v + ((size_t)(b * p.KH + kvh) * p.KL) * E);
+    const uint8_t* __restrict__ mp = kGeneral && p.kpad ? p.kpad + (size_t)b * p.KL : nullptr;
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const uint32_t kring = lds0, vring = lds0 + NS * KBYTES;
+    uint64_t* const vbits = reinterpret_cast<uint64_t*>(smem + MASK_OFF + 16);
+
+    // ---- number of kv tiles (workgroup) / live tiles (this wave): as in fa_fwd_w64.hpp ---------------------------------------------
+    int n_tiles = (p.KL + BK - 1) / BK;
+    int causal_q0 = 0x3fffffff;
+    int qlim[2] = {0x3fffffff, 0x3fffffff};
+    if constexpr (kGeneral) {
+        if (p.causal) {
+            int q_last = qblk * 256 + 255;
+            if (q_last > p.QL - 1) q_last = p.QL - 1;
+            const int t_c = q_last / BK + 1;
+            if (t_c < n_tiles) n_tiles = t_c;
+            causal_q0 = q0w;
+            qlim[0] = qi[0];
+            qlim[1] = qi[1];
+        }
+        if (mp) {
+            int* slot = reinterpret_cast<int*>(smem + MASK_OFF);
+            const int nk = n_tiles * BK < p.KL ? n_tiles * BK : p.KL;
+            const int last = kpad_scan(mp, p.KL, nk, vbits, kMaxMaskTiles, slot, tid, 512);
+            const int t_m = last / BK + 1;
+            if (t_m < n_tiles) n_tiles = t_m;
+        } else {
+            for (int w = tid; w < n_tiles; w += 512) {
+                const int left = p.KL - w * BK;
+                vbits[w] = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            }
+            __syncthreads();
+        }
+    }
+    int n_live = n_tiles;
+    if (kGeneral && p.causal) {
+        const int t_w = (q0w + 63) / BK + 1;
+        if (t_w < n_live) n_live = t_w;
+    }
+
+    // ---- per-lane DMA source offsets inside a tile (the image's layout applied to the SOURCE; fa_fwd_w64.hpp) ---------------------
+    uint32_t k_voff[NJK];
+#pragma unroll
+    for (int j = 0; j < NJK; ++j) {
+        const int off = (wq * NJK + j) * 1024 + lane * 16;
+        const int row = off / KImg::kRowBytes, phys = (off % KImg::kRowBytes) >> 4;
+        k_voff[j] = (uint32_t)(row * KImg::kRowBytes + ((phys ^ KImg::xor_of(row)) << 4) - j * 1024);
+    }
+    uint32_t v_voff;
+    {
+        const int off = (wq * NJV) * 1024 + lane * 16;
+        const int blk = off >> 8, rg = blk / VImg::kEB, eb = blk % VImg::kEB, rr = (off >> 6) & 3, c4 = (off >> 4) & 3;
+        v_voff = (uint32_t)((4 * rg + rr) * KImg::kRowBytes + ((4 * eb + c4) << 4));
+    }
+    static_assert((1024 / 256) % VImg::kEB == 0 && (4 * (1024 / 256 / VImg::kEB)) * VImg::kRowBytes == 1024, "V image: 1 KiB = whole row groups");
+    const uint32_t wave_off_k = (uint32_t)(wq * NJK * 1024), wave_off_v = (uint32_t)(wq * NJV * 1024);
+    const uint32_t kv_bytes = (uint32_t)p.KL * (uint32_t)KImg::kRowBytes;
+    const u32x4 krs = make_rsrc(kp, kv_bytes), vrs = make_rsrc(vp, kv_bytes);
+    // past the last tile the LAST tile is copied again (into a ring slot nobody reads any more): no branch around an issue
+    auto tile_off = [&](int t) -> uint32_t { return (uint32_t)(t < n_tiles ? t : n_tiles - 1) * (uint32_t)TILE_BYTES; };
+    auto issue_k_piece = [&](uint32_t soff, uint32_t dst, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        dma_piece<j, j == 0>(krs, k_voff[j], soff, dst);
+    };
+    // ring slots (LDS byte address + this wave's DMA share) of tiles t, t + 1, t + 2 (mod 3), rotated by two per iteration
+    const int s0 = grp;                                       // t = grp at the start
+    uint32_t kX = kring + wave_off_k + (uint32_t)(s0 % 3) * KBYTES, kY = kring + wave_off_k + (uint32_t)((s0 + 1) % 3) * KBYTES,
+             kZ = kring + wave_off_k + (uint32_t)((s0 + 2) % 3) * KBYTES;
+    uint32_t vX = vring + wave_off_v + (uint32_t)(s0 % 3) * VBYTES, vY = vring + wave_off_v + (uint32_t)((s0 + 1) % 3) * VBYTES,
+             vZ = vring + wave_off_v + (uint32_t)((s0 + 2) % 3) * VBYTES;
+    // ragged KL: rows of the last tile past KL are outside the descriptor's range -- the ring must not hold non-finite garbage there
+    if (kGeneral && (p.KL & (BK - 1)) != 0) {
+        for (int i = tid * 16; i < RING; i += 512 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+        __syncthreads();
+    }
+    // ---- prologue: the group's first K tile in flight; Q fragments straight into the accumulator file -----------------------------
+    {
+        const uint32_t so = tile_off(grp);
+        static_for<NJK>([&](auto jc) { issue_k_piece(so, kX, jc); });
+    }
+    const float c2 = p.scale * kLog2e;
+    f32x16 qf[2];                                             // the 4 fragments (16-deep steps of E) of query block z, as one tuple
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+        const int qc = qi[z] < p.QL ? qi[z] : p.QL - 1;
+        const T* qrow = qp + (size_t)qc * E;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(qrow + 16 * ks + 8 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qf[z][4 * ks + i] = w[i];
+        }
+    }
+    f32x16 oacc[2][EB];
+    f32x4 lacc[2];                                            // row sums: registers 0 / 1 of lanes 0..15 = queries lane, lane + 16 (SumMfma)
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[z][eb][i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lacc[z][i] = 0.f;
+    }
+    // Row sums of P on the matrix pipe with the 16x16x32 shape: half the pipe time and a quarter of the accumulator registers of a
+    // ones x P^T product in the 32x32x16 shape.  The B operand is a P^T fragment AS IT IS (lane (r, h) = lane l: 8 keys of query r): the
+    // 16x16x32 instruction reads lane l as column l % 16, contraction group l / 16, i.e. it would add queries r and r + 16 together --
+    // unless the A operand separates them: row m of A is one where contraction group g has g % 2 == m (rows 2..15 zero), so
+    //   D[0][n] = sum over the keys of query n,   D[1][n] = the same for query n + 16      (n = 0..15),
+    // which land in accumulator registers 0 and 1 of lanes 0..15 (the other lanes and registers hold zero rows).
+    f32x4 sel;
+    {
+        frag_t sf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sf[j] = from_f32<T>((((lane >> 4) & 1) == (lane & 15)) ? 1.0f : 0.0f);
+        sel = __builtin_bit_cast(f32x4, sf);
+    }
+    const uint32_t k_lane = (uint32_t)(r * KImg::kRowBytes + ((KImg::xor_of(r) ^ h) << 4)) - wave_off_k;
+    const uint32_t v_lane = (uint32_t)VImg::lane_base(lane) - wave_off_v;
+    // K(grp) and Q landed (every wave's pieces: barrier).  The Q fragments pass through the statement.
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : "+v"(qf[0]), "+v"(qf[1]) :: "memory");
+#if NNOP_DUO_STAMP
+    stamp[2] = __builtin_amdgcn_s_memtime();
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // the score tile S(t)^T: [z][key block].  V(t) packs P(t)^T IN PLACE: the 8 logits of 16-key step kk (registers 8 (kk & 1) .. + 7 of
+    // sc[z][kk >> 1]) become 4 operand words in the first 4 of those registers.
+    f32x16 sc[2][KB];
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[z][kb][i] = 0.f;
+
+    // ---- the phase loop (generated, tools/gen_duo_asm.py): half-steps h = 0 .. n_tiles + 1, one barrier each; group g runs the matrix
+    // phase M(t) at h = t for t = g (mod 2) -- [row sums of P(t-2)] [O += V(t-2)^T P(t-2)^T] [S(t) = K(t) Q^T], the LDS-DMA of K(t+2) and
+    // V(t) in its gaps -- and the vector phase V(t) at h = t + 1: mask, row max, (rare) raise of the reference, P = exp2(s c - m) packed
+    // as MFMA operand words ------------------------------------------------------------------------------------------------------------
+    f32x4 mstate = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};       // m2[0..1] (exponent reference), mt[0..1] (true row max)
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    u32x8 vconst;
+    vconst[0] = k_voff[0]; vconst[1] = k_voff[1]; vconst[2] = v_voff; vconst[3] = k_lane; vconst[4] = v_lane;
+    vconst[5] = (uint32_t)qlim[0]; vconst[6] = (uint32_t)qlim[1]; vconst[7] = (uint32_t)(4 * h);
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    u32x16 sstate;
+    {
+        auto sgpr = [](uint32_t x) { return x; };           // (wave-uniform values; the statement moves them to scalar registers itself)
+        const int H = n_tiles + 2;
+        sstate[0] = sgpr((uint32_t)grp); sstate[1] = sgpr((uint32_t)H); sstate[2] = sgpr((uint32_t)n_live);
+        sstate[3] = sgpr(kX); sstate[4] = sgpr(kY); sstate[5] = sgpr(kZ); sstate[6] = sgpr(vX); sstate[7] = sgpr(vY); sstate[8] = sgpr(vZ);
+        sstate[9] = sgpr((uint32_t)(n_tiles - 1) * (uint32_t)TILE_BYTES);
+        sstate[10] = sgpr(__float_as_uint(c2)); sstate[11] = sgpr((uint32_t)causal_q0);
+        sstate[12] = sgpr((uint32_t)(uintptr_t)vbits);
+        sstate[13] = 0; sstate[14] = 0; sstate[15] = 0;
+    }
+#if NNOP_DUO_PRIO == 2
+    if (grp) __builtin_amdgcn_s_setprio(1);
+#endif
+    if (grp) asm volatile("s_barrier" ::: "memory");          // half-step 0: group 1 has nothing to do yet
+    if constexpr (std::is_same<T, __bf16>::value) {
+        if constexpr (kGeneral) asm volatile(NNOP_DUO_LOOP_MASKED("bf16") : NNOP_DUO_OPERANDS);
+        else asm volatile(NNOP_DUO_LOOP_PLAIN("bf16") : NNOP_DUO_OPERANDS);
+    } else {
+        if constexpr (kGeneral) asm volatile(NNOP_DUO_LOOP_MASKED("f16") : NNOP_DUO_OPERANDS);
+        else asm volatile(NNOP_DUO_LOOP_PLAIN("f16") : NNOP_DUO_OPERANDS);
+    }
+    float m2[2] = {mstate[0], mstate[1]}, mt[2] = {mstate[2], mstate[3]};
+#if NNOP_DUO_STAMP
+    stamp[4] = __builtin_amdgcn_s_memtime();
+    stamp[5] = __builtin_amdgcn_s_memrealtime();
+#endif
+    // the rings are dead from here on (the exchange buffer overlays them): every DMA landed, every wave past its last fragment read
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- epilogue: the partners exchange one 32-row half each through LDS, merge the two key groups, normalise, store --------------
+    asm volatile(NNOP_FENCE_128 ::: "memory");                // the last MFMAs have written O and the row sums
+    __builtin_amdgcn_sched_barrier(0);
+    // wave w writes the half it gives away into its own exchange block; after the barrier it reads its partner's block (the other
+    // key group's partial result for the rows it keeps)
+    char* const mine = smem + wave * (8192 + 3 * 256);
+    const char* const theirs = smem + (wave ^ 4) * (8192 + 3 * 256);
+    auto row_sum = [&](const f32x4& l) -> float {            // this lane's query r: lane r % 16, register r / 16
+        const float l0 = __shfl(l[0], r & 15), l1 = __shfl(l[1], r & 15);
+        return (r & 16) ? l1 : l0;
+    };
+    auto give = [&](auto givec) {
+        constexpr int ZG = decltype(givec)::value;
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 w = {oacc[ZG][eb][4 * g4], oacc[ZG][eb][4 * g4 + 1], oacc[ZG][eb][4 * g4 + 2], oacc[ZG][eb][4 * g4 + 3]};
+                *reinterpret_cast<f32x4*>(mine + ((eb * 4 + g4) * 64 + lane) * 16) = w;
+            }
+        }
+        float* sm = reinterpret_cast<float*>(mine + 8192);
+        sm[lane] = row_sum(lacc[ZG]);
+        sm[64 + lane] = m2[ZG];
+        sm[128 + lane] = mt[ZG];
+    };
+    auto take = [&](auto keepc) {
+        constexpr int ZK = decltype(keepc)::value;
+        const float* so_ = reinterpret_cast<const float*>(theirs + 8192);
+        const float l_o = so_[lane], m_o = so_[64 + lane], mt_o = so_[128 + lane];
+        const float l_m = row_sum(lacc[ZK]), m_m = m2[ZK];
+        const float mm = fmaxf(m_m, m_o);
+        const float a = m_m == -INFINITY ? 0.f : fast_exp2(m_m - mm);
+        const float bsc = m_o == -INFINITY ? 0.f : fast_exp2(m_o - mm);
+        const float ltot = a * l_m + bsc * l_o;
+        const float mtt = fmaxf(mt[ZK], mt_o);
+        const float inv = 1.0f / ltot;                       // ltot == 0 (no visible key) -> NaN rows, as the naive formula gives
+        const float ai = a * inv, bi = bsc * inv;
+        T* orow = (T*)p.o + ((size_t)bh * p.QL + (qi[ZK] < p.QL ? qi[ZK] : p.QL - 1)) * E;
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb) {
+            uint32_t pk[4][2];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                typedef T t4 __attribute__((ext_vector_type(4)));
+                const f32x4 ot = *reinterpret_cast<const f32x4*>(theirs + ((eb * 4 + g4) * 64 + lane) * 16);
+                const f32x4 w = {oacc[ZK][eb][4 * g4] * ai + ot[0] * bi, oacc[ZK][eb][4 * g4 + 1] * ai + ot[1] * bi,
+                                 oacc[ZK][eb][4 * g4 + 2] * ai + ot[2] * bi, oacc[ZK][eb][4 * g4 + 3] * ai + ot[3] * bi};
+                const u32x2 u = __builtin_bit_cast(u32x2, __builtin_convertvector(w, t4));
+                pk[g4][0] = u[0];
+                pk[g4][1] = u[1];
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4 += 2) {
+                // lanes 0-31 end up with e = 32 eb + 8 g + (0..7), lanes 32-63 with e = 32 eb + 8 (g+1) + (0..7)
+                const auto x0 = __builtin_amdgcn_permlane32_swap(pk[g4][0], pk[g4 + 1][0], false, false);
+                const auto x1 = __builtin_amdgcn_permlane32_swap(pk[g4][1], pk[g4 + 1][1], false, false);
+                const u32x4 lo = {x0[0], x1[0], x0[1], x1[1]};
+                if (qi[ZK] < p.QL) *reinterpret_cast<u32x4*>(orow + 32 * eb + 8 * g4 + 8 * h) = lo;
+            }
+        }
+        if (qi[ZK] < p.QL && h == 0) {
+            // residual contract (src/attention.jl:128-129): ms = row max (natural-log units) rounded to T, ls relative to the ROUNDED ms
+            const size_t so = (size_t)bh * p.QL + qi[ZK];
+            const T m_t = from_f32<T>(mtt * kLn2);
+            const float m_back = to_f32(m_t);
+            float l_out = ltot;
+            if (mtt != -INFINITY) l_out = ltot * fast_exp2(mm - m_back * kLog2e);
+            ((T*)p.ms)[so] = m_t;
+            ((T*)p.ls)[so] = from_f32<T>(l_out);
+        }
+    };
+    // group 0 keeps the rows of z = 0 and gives z = 1 away, group 1 the other way round
+    if (grp == 0) give(std::integral_constant<int, 1>{});
+    else give(std::integral_constant<int, 0>{});
+    __syncthreads();
+    if (grp == 0) take(std::integral_constant<int, 0>{});
+    else take(std::integral_constant<int, 1>{});
+#if NNOP_DUO_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[6] = __builtin_amdgcn_s_memtime();
+    stamp[7] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+        uint64_t* dbg = reinterpret_cast<uint64_t*>((T*)p.o + ((size_t)bh * p.QL + q0w) * E);
+        for (int i = 0; i < 8; ++i) dbg[i] = stamp[i];
+        dbg[8] = (uint64_t)n_tiles;
+        dbg[9] = stamp[2];
+        dbg[10] = stamp[2];
+    }
+#endif
+}
+
+}  // namespace nnop

@@ -9,6 +9,7 @@
 #include "fa_fwd.hpp"
 #include "fa_fwd_split.hpp"
 #include "fa_fwd_w64.hpp"
+#include "fa_fwd_duo.hpp"
 #include "fa_generic.hpp"
 #ifdef NNOP_DEV_BUILD
 #include <stdlib.h>
@@ -131,6 +132,28 @@ static int launch_fwd_w64(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
+// two waves per SIMD in alternating phases (fa_fwd_duo.hpp): 8 waves, 256 query rows per workgroup, 16-bit types, E = 64
+template <typename T, int E, int MODE>
+static int launch_fwd_duo(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
+    constexpr int lds = fa_fwd_duo_lds_bytes<T, E>(MODE != 0);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = fa_fwd_duo_kernel<T, E, MODE>;
+    static unsigned long long lds_done = 0;
+    if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
+    FwdParams p;
+    p.o = a.o; p.ms = a.ms; p.ls = a.ls;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.pair = nullptr; p.kpad = a.kpad;
+    p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
+    p.causal = d.causal ? 1 : 0;
+    p.n_qblk = (d.ql + 255) / 256;
+    const long long n_wg = (long long)p.n_qblk * d.qh * d.batch;
+    if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    p.n_wg = (int)n_wg;
+    p.scale = (float)(1.0 / sqrt((double)E));
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), lds, s, p);
+    return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
+}
+
 template <typename T, int E, int NW, int QB>
 static int launch_fwd_mode(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s, int mode) {
     if (mode == 0) return launch_fwd_cfg<T, E, NW, 0, QB>(d, a, s);
@@ -170,6 +193,12 @@ static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
         const bool masked = mode == 1;
         const bool pays = E == 128 ? (d.kl >= 256 && (wg256 >= 160 || (masked && wg256 >= 64)))
                                    : (masked ? (d.kl >= 512 && wg256 >= 128) : (d.kl >= 256 && wg256 >= 64));
+        // E = 64, exact scale: two waves per SIMD in alternating phases (fa_fwd_duo.hpp).  Knob kTuneFwdDuo: 0 never, 1 wherever
+        // instantiated, auto = off for now.
+        if (E == 64 && fits && tune_get(kTuneFwdExactScale) != 0) {
+            const int duo = tune_get(kTuneFwdDuo);
+            if (duo == 1) return kFormDuo;
+        }
         if (fits && (w64 == 1 || (w64 < 0 && pays))) return kFormW64;
     }
     if (b16 && E <= 64) {
@@ -189,6 +218,9 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
     if constexpr (sizeof(T) == 2 && E == 256) {
         if (form == kFormW64) return mode == 0 ? launch_fwd_w64<T, E, 0, false>(d, a, s) : launch_fwd_w64<T, E, 1, false>(d, a, s);    // exact scale only
+    }
+    if constexpr (sizeof(T) == 2 && E == 64) {
+        if (form == kFormDuo) return mode == 0 ? launch_fwd_duo<T, E, 0>(d, a, s) : launch_fwd_duo<T, E, 1>(d, a, s);
     }
     if constexpr (sizeof(T) == 2 && (E == 64 || E == 128)) {
         if (form == kFormW64) {

@@ -25,8 +25,8 @@ struct BwdArgs {
 // One per dtype (fa_fwd_{f32,f16,bf16}.hip).  Return an nnop_status.
 template <typename T> int launch_fwd(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s);
 // Which kernel form launch_fwd picks (no launch): 0 = 32-row waves, 1 = split-KV, 2 = 64-row waves, 3 = the plain-HIP kernel of
-// fa_generic.hpp (embedding dims outside the tiled set).
-enum FwdForm { kFormRow32 = 0, kFormSplit = 1, kFormW64 = 2, kFormGeneric = 3 };
+// fa_generic.hpp (embedding dims outside the tiled set), 4 = two waves per SIMD in alternating phases (fa_fwd_duo.hpp).
+enum FwdForm { kFormRow32 = 0, kFormSplit = 1, kFormW64 = 2, kFormGeneric = 3, kFormDuo = 4 };
 int fwd_form(const nnop_fa_desc& d, bool has_pair, bool has_mask);
 // Which backward kernels launch_bwd picks (no launch): bit 0: dK/dV on fa_bwd_w64_kernel, bit 1: dQ on it (else fa_bwd.hpp's)
 int bwd_forms(const nnop_fa_desc& d, bool has_pair);

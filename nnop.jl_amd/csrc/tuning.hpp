@@ -24,6 +24,7 @@ enum TuneKey {
     kTuneBwdStages,      // (no environment variable; nnop_debug_set only)  measurement only: which passes of the tiled backward run (bit mask: 1 preprocess, 2 dK/dV, 4 dQ)
     kTuneFwdPersist,     // NNOP_FWD_PERSIST 64-row forward as 256 persistent workgroups that walk a static block list: 0 never, 1 / auto wherever the list balances
     kTuneBwdPersist,     // NNOP_BWD_PERSIST the same for the one-wave-per-SIMD backward kernels
+    kTuneFwdDuo,         // NNOP_FWD_DUO     two-waves-per-SIMD alternating-phase forward (fa_fwd_duo.hpp, 16-bit E = 64): 0 never, 1 wherever instantiated
     kTuneCount
 };
 
