@@ -52,17 +52,18 @@ namespace nnop {
 #define NNOP_DUO_OPERANDS                                                                                                        \
     "+{v[0:15]}"(oacc[0][0]), "+{v[16:31]}"(oacc[0][1]), "+{v[32:47]}"(oacc[1][0]), "+{v[48:63]}"(oacc[1][1]), "+{v[64:79]}"(qf[0]),   \
         "+{v[80:95]}"(qf[1]), "+{v[96:99]}"(lacc[0]), "+{v[100:103]}"(lacc[1]), "+{v[104:107]}"(sel), "+{v[112:127]}"(sc[0][0]),      \
-        "+{v[128:143]}"(sc[0][1]), "+{v[144:159]}"(sc[1][0]), "+{v[160:175]}"(sc[1][1]), "+{v[192:195]}"(mstate)                         \
-        : "{v[196:203]}"(vconst), "{v[224:239]}"(sstate), "{v[240:243]}"(krs), "{v[244:247]}"(vrs)                                 \
+        "+{v[128:143]}"(sc[0][1]), "+{v[144:159]}"(sc[1][0]), "+{v[160:175]}"(sc[1][1]), "+{v[192:195]}"(mstate), "+{v[224:239]}"(sstate), \
+        "+{v[240:243]}"(krs_io), "+{v[244:247]}"(vrs_io)                                                                           \
+        : "{v[196:203]}"(vconst)                                                                                                   \
         : "memory", "vcc", "scc", "v108", "v109", "v110", "v111", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", \
           "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212",   \
           "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "s56", "s57", "s58", "s59", "s60", "s61",  \
-          "s62", "s63", "s64", "s65", "s66", "s67", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", \
-          "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55"
+          "s62", "s63", "s64", "s65", "s66", "s67", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s77", \
+          "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76"
 
 constexpr int kDuoXchgBytes = 8 * (8192 + 3 * 256);          // epilogue exchange: per wave 32 fp32 per lane + (l, m2, mt)
 template <typename T, int E> constexpr int fa_fwd_duo_lds_bytes(bool masked) {
-    constexpr int ring = 3 * (RowImg<T, E>::bytes(64) + ColImg<T, E>::bytes(64));
+    constexpr int ring = 2 * NNOP_DUO_SLOTS_PER_GROUP * (RowImg<T, E>::bytes(64) + ColImg<T, E>::bytes(64));
     return (ring > kDuoXchgBytes ? ring : kDuoXchgBytes) + (masked ? 16 + 8 * kMaxMaskTiles : 0);
 }
 
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     using VImg   = ColImg<T, E>;
     using MM     = MfmaAsm<T>;
     constexpr bool kGeneral = MODE != 0;
-    constexpr int BK = 64, KB = 2, KS = E / 16, EB = E / 32, NS = 3;
+    constexpr int BK = 64, KB = 2, KS = E / 16, EB = E / 32, NS = 2 * NNOP_DUO_SLOTS_PER_GROUP;
     constexpr int KBYTES = KImg::bytes(BK), VBYTES = VImg::bytes(BK);
     constexpr int RING = NS * (KBYTES + VBYTES);
     constexpr int MASK_OFF = RING > kDuoXchgBytes ? RING : kDuoXchgBytes;
@@ -171,22 +172,20 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         constexpr int j = decltype(jc)::value;
         dma_piece<j, j == 0>(krs, k_voff[j], soff, dst);
     };
-    // ring slots (LDS byte address + this wave's DMA share) of tiles t, t + 1, t + 2 (mod 3), rotated by two per iteration
-    const int s0 = grp;                                       // t = grp at the start
-    uint32_t kX = kring + wave_off_k + (uint32_t)(s0 % 3) * KBYTES, kY = kring + wave_off_k + (uint32_t)((s0 + 1) % 3) * KBYTES,
-             kZ = kring + wave_off_k + (uint32_t)((s0 + 2) % 3) * KBYTES;
-    uint32_t vX = vring + wave_off_v + (uint32_t)(s0 % 3) * VBYTES, vY = vring + wave_off_v + (uint32_t)((s0 + 1) % 3) * VBYTES,
-             vZ = vring + wave_off_v + (uint32_t)((s0 + 2) % 3) * VBYTES;
+    // Rings of NS slots, NS / 2 per key group.  At iteration t (LDS byte address + this wave's DMA share): kA = slot of K(t), read in M(t);
+    // kB = slot of K(t+2); kC = the free slot, target of K(t+4) (with 2 slots per group: kA again, and the batch is then issued behind the
+    // barrier that closes M(t)).  vA = slot of V(t-2), read in M(t); vB = slot of V(t); vC = free, target of V(t+2).  The group's slots
+    // rotate (A, B, C) <- (B, C, A) per iteration.
+    constexpr int SPG = NNOP_DUO_SLOTS_PER_GROUP;
+    const uint32_t kA = kring + wave_off_k + (uint32_t)(SPG * grp) * KBYTES, kB = kA + KBYTES, kC = kA + (SPG - 1) * KBYTES;
+    const uint32_t vA = vring + wave_off_v + (uint32_t)(SPG * grp) * VBYTES, vB = vA + VBYTES, vC = vA + (SPG - 1) * VBYTES;
     // ragged KL: rows of the last tile past KL are outside the descriptor's range -- the ring must not hold non-finite garbage there
     if (kGeneral && (p.KL & (BK - 1)) != 0) {
         for (int i = tid * 16; i < RING; i += 512 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
         __syncthreads();
     }
-    // ---- prologue: the group's first K tile in flight; Q fragments straight into the accumulator file -----------------------------
-    {
-        const uint32_t so = tile_off(grp);
-        static_for<NJK>([&](auto jc) { issue_k_piece(so, kX, jc); });
-    }
+    // ---- prologue: the group's first tiles in flight -- K(g), K(g+2), V(g) (the loop's first batch is K(g+4), V(g+2)) -----------------
+    static_for<NJK>([&](auto jc) { issue_k_piece(tile_off(grp), kA, jc); });
     const float c2 = p.scale * kLog2e;
     f32x16 qf[2];                                             // the 4 fragments (16-deep steps of E) of query block z, as one tuple
 #pragma unroll
@@ -224,6 +223,11 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         for (int j = 0; j < 8; ++j) sf[j] = from_f32<T>((((lane >> 4) & 1) == (lane & 15)) ? 1.0f : 0.0f);
         sel = __builtin_bit_cast(f32x4, sf);
     }
+    static_for<NJK>([&](auto jc) { issue_k_piece(tile_off(grp + 2), kB, jc); });
+    static_for<NJV>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        dma_piece<j, j == 0>(vrs, v_voff, tile_off(grp), vB);
+    });
     const uint32_t k_lane = (uint32_t)(r * KImg::kRowBytes + ((KImg::xor_of(r) ^ h) << 4)) - wave_off_k;
     const uint32_t v_lane = (uint32_t)VImg::lane_base(lane) - wave_off_v;
     // K(grp) and Q landed (every wave's pieces: barrier).  The Q fragments pass through the statement.
@@ -258,24 +262,39 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         auto sgpr = [](uint32_t x) { return x; };           // (wave-uniform values; the statement moves them to scalar registers itself)
         const int H = n_tiles + 2;
         sstate[0] = sgpr((uint32_t)grp); sstate[1] = sgpr((uint32_t)H); sstate[2] = sgpr((uint32_t)n_live);
-        sstate[3] = sgpr(kX); sstate[4] = sgpr(kY); sstate[5] = sgpr(kZ); sstate[6] = sgpr(vX); sstate[7] = sgpr(vY); sstate[8] = sgpr(vZ);
+        sstate[3] = sgpr(kA); sstate[4] = sgpr(kB); sstate[5] = sgpr(kC); sstate[6] = sgpr(vA); sstate[7] = sgpr(vB); sstate[8] = sgpr(vC);
         sstate[9] = sgpr((uint32_t)(n_tiles - 1) * (uint32_t)TILE_BYTES);
         sstate[10] = sgpr(__float_as_uint(c2)); sstate[11] = sgpr((uint32_t)causal_q0);
         sstate[12] = sgpr((uint32_t)(uintptr_t)vbits);
         sstate[13] = 0; sstate[14] = 0; sstate[15] = 0;
     }
+    u32x4 krs_io = krs, vrs_io = vrs;                          // (the statement overwrites its input registers with P words)
 #if NNOP_DUO_PRIO == 2
     if (grp) __builtin_amdgcn_s_setprio(1);
 #endif
     if (grp) asm volatile("s_barrier" ::: "memory");          // half-step 0: group 1 has nothing to do yet
+#if NNOP_DUO_STAMP
+#define NNOP_DUO_LOOP_MASKED NNOP_DUO_LOOP_MASKED_PROF
+#define NNOP_DUO_LOOP_PLAIN NNOP_DUO_LOOP_PLAIN_PROF
+#endif
+    // (experiments, make DEV=1 VAR=-DNNOP_DUO_PRIO=n: 1 matrix phase at s_setprio 1, 2 waves 4-7 at priority 1 throughout, 3 vector phase at 1)
+#if NNOP_DUO_PRIO == 1
+#define NNOP_DUO_PRIO_ARGS "s_setprio 1", "s_setprio 0", "", ""
+#elif NNOP_DUO_PRIO == 3
+#define NNOP_DUO_PRIO_ARGS "", "", "s_setprio 1", "s_setprio 0"
+#else
+#define NNOP_DUO_PRIO_ARGS "", "", "", ""
+#endif
+#define NNOP_DUO_X(M, ...) M(__VA_ARGS__)
     if constexpr (std::is_same<T, __bf16>::value) {
-        if constexpr (kGeneral) asm volatile(NNOP_DUO_LOOP_MASKED("bf16") : NNOP_DUO_OPERANDS);
-        else asm volatile(NNOP_DUO_LOOP_PLAIN("bf16") : NNOP_DUO_OPERANDS);
+        if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_MASKED, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
+        else asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_PLAIN, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
     } else {
-        if constexpr (kGeneral) asm volatile(NNOP_DUO_LOOP_MASKED("f16") : NNOP_DUO_OPERANDS);
-        else asm volatile(NNOP_DUO_LOOP_PLAIN("f16") : NNOP_DUO_OPERANDS);
+        if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_MASKED, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
+        else asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_PLAIN, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
     }
-    float m2[2] = {mstate[0], mstate[1]}, mt[2] = {mstate[2], mstate[3]};
+    // (the loop keeps the true row max per lane half -- lane l ^ 32 holds the same query's other keys: combined here, once)
+    float m2[2] = {mstate[0], mstate[1]}, mt[2] = {half_swap_max(mstate[2]), half_swap_max(mstate[3])};
 #if NNOP_DUO_STAMP
     stamp[4] = __builtin_amdgcn_s_memtime();
     stamp[5] = __builtin_amdgcn_s_memrealtime();
@@ -371,6 +390,11 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         dbg[8] = (uint64_t)n_tiles;
         dbg[9] = stamp[2];
         dbg[10] = stamp[2];
+        for (int i = 0; i < 5; ++i) dbg[11 + i] = (uint64_t)sstate[i];     // cycles in M, barrier, V, DMA wait, barrier (wave 0)
+    }
+    if (tid == 256) {                                         // the same five of wave 4 (key group 1), in the block's second row
+        uint64_t* dbg = reinterpret_cast<uint64_t*>((T*)p.o + ((size_t)bh * p.QL + q0w + 1) * E);
+        for (int i = 0; i < 5; ++i) dbg[i] = (uint64_t)sstate[i];
     }
 #endif
 }
