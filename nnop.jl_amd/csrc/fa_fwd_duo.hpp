@@ -49,17 +49,22 @@
 namespace nnop {
 
 // Operands of the generated loop statement: every tile in its home register (register map: tools/gen_duo_asm.py)
+#if NNOP_DUO_STAMP
+#define NNOP_DUO_PROF_OPERAND , "+{v[224:231]}"(profv)
+#else
+#define NNOP_DUO_PROF_OPERAND
+#endif
 #define NNOP_DUO_OPERANDS                                                                                                        \
     "+{v[0:15]}"(oacc[0][0]), "+{v[16:31]}"(oacc[0][1]), "+{v[32:47]}"(oacc[1][0]), "+{v[48:63]}"(oacc[1][1]), "+{v[64:79]}"(qf[0]),   \
         "+{v[80:95]}"(qf[1]), "+{v[96:99]}"(lacc[0]), "+{v[100:103]}"(lacc[1]), "+{v[104:107]}"(sel), "+{v[112:127]}"(sc[0][0]),      \
-        "+{v[128:143]}"(sc[0][1]), "+{v[144:159]}"(sc[1][0]), "+{v[160:175]}"(sc[1][1]), "+{v[192:195]}"(mstate), "+{v[224:239]}"(sstate), \
-        "+{v[240:243]}"(krs_io), "+{v[244:247]}"(vrs_io)                                                                           \
-        : "{v[196:203]}"(vconst)                                                                                                   \
+        "+{v[128:143]}"(sc[0][1]), "+{v[144:159]}"(sc[1][0]), "+{v[160:175]}"(sc[1][1]), "+{v[192:195]}"(mstate), [st] "+s"(s_t),      \
+        [ska] "+s"(s_ka), [skb] "+s"(s_kb), [skc] "+s"(s_kc), [sva] "+s"(s_va), [svb] "+s"(s_vb), [svc] "+s"(s_vc) NNOP_DUO_PROF_OPERAND \
+        : "{v[196:203]}"(vconst), [sh] "s"(s_h), [snlive] "s"(s_nlive), [slast] "s"(s_last), [sc2] "s"(c2), [scq0] "s"(s_cq0),            \
+          [svbits] "s"(s_vbits), [krs] "s"(krs), [vrs] "s"(vrs)                                                                       \
         : "memory", "vcc", "scc", "v108", "v109", "v110", "v111", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", \
           "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212",   \
           "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "s56", "s57", "s58", "s59", "s60", "s61",  \
-          "s62", "s63", "s64", "s65", "s66", "s67", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s77", \
-          "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76"
+          "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77"
 
 constexpr int kDuoXchgBytes = 8 * (8192 + 3 * 256);          // epilogue exchange: per wave 32 fp32 per lane + (l, m2, mt)
 template <typename T, int E> constexpr int fa_fwd_duo_lds_bytes(bool masked) {
@@ -94,10 +99,25 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     const int grp = wave >> 2, wq = wave & 3;                 // key group (tile parity) / 64-row slice of the block
     const int r = lane & 31, h = lane >> 5;
 
-    const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_qblk * (p.QH / p.KH));
-    int qblk = lin % p.n_qblk;
-    const int bh = lin / p.n_qblk;
-    if (kGeneral && p.causal) qblk = p.n_qblk - 1 - qblk;     // heaviest q-blocks first
+    // ---- persistent form (p.persist = blocks per workgroup; 0: one block per workgroup): the static, balanced block list of
+    // fa_fwd_w64.hpp -- XCD x owns an eighth of the (batch, q-head) columns, its blocks (q-blocks descending inside a column) are dealt
+    // out 32 at a time alternately forwards and backwards over its 32 workgroups ----------------------------------------------------
+    const int n_steps_pers = (kGeneral && p.persist > 0) ? p.persist : 1;
+    for (int pstep = 0; pstep < n_steps_pers; ++pstep) {
+    int qblk, bh;
+    if (kGeneral && p.persist > 0) {
+        const int x = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3;
+        const int pos = 32 * pstep + ((pstep & 1) ? 31 - c : c);
+        const int col = pos / p.n_qblk;
+        qblk = p.n_qblk - 1 - (pos - col * p.n_qblk);
+        if (p.persist_hx > 0) bh = (col / p.persist_hx) * p.QH + x * p.persist_hx + col % p.persist_hx;
+        else bh = x * ((p.B * p.QH) >> 3) + col;
+    } else {
+        const int lin = xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_qblk * (p.QH / p.KH));
+        qblk = lin % p.n_qblk;
+        bh = lin / p.n_qblk;
+        if (kGeneral && p.causal) qblk = p.n_qblk - 1 - qblk; // heaviest q-blocks first
+    }
     const int b = bh / p.QH, qh = bh - b * p.QH;
     const int kvh = qh / (p.QH / p.KH);                       // cld(q_head, n_q_per_kv), 0-based (src/attention.jl:28)
     const int q0w = qblk * 256 + wq * 64;                     // first query row of this wave (and of its partner)
@@ -256,19 +276,13 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     u32x8 vconst;
     vconst[0] = k_voff[0]; vconst[1] = k_voff[1]; vconst[2] = v_voff; vconst[3] = k_lane; vconst[4] = v_lane;
     vconst[5] = (uint32_t)qlim[0]; vconst[6] = (uint32_t)qlim[1]; vconst[7] = (uint32_t)(4 * h);
-    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-    u32x16 sstate;
-    {
-        auto sgpr = [](uint32_t x) { return x; };           // (wave-uniform values; the statement moves them to scalar registers itself)
-        const int H = n_tiles + 2;
-        sstate[0] = sgpr((uint32_t)grp); sstate[1] = sgpr((uint32_t)H); sstate[2] = sgpr((uint32_t)n_live);
-        sstate[3] = sgpr(kA); sstate[4] = sgpr(kB); sstate[5] = sgpr(kC); sstate[6] = sgpr(vA); sstate[7] = sgpr(vB); sstate[8] = sgpr(vC);
-        sstate[9] = sgpr((uint32_t)(n_tiles - 1) * (uint32_t)TILE_BYTES);
-        sstate[10] = sgpr(__float_as_uint(c2)); sstate[11] = sgpr((uint32_t)causal_q0);
-        sstate[12] = sgpr((uint32_t)(uintptr_t)vbits);
-        sstate[13] = 0; sstate[14] = 0; sstate[15] = 0;
-    }
-    u32x4 krs_io = krs, vrs_io = vrs;                          // (the statement overwrites its input registers with P words)
+    // the loop's scalar state (wave-uniform: hipcc hands them over in scalar registers)
+    int s_t = grp, s_h = n_tiles + 2, s_nlive = n_live, s_cq0 = causal_q0;
+    uint32_t s_ka = kA, s_kb = kB, s_kc = kC, s_va = vA, s_vb = vB, s_vc = vC;
+    const uint32_t s_last = (uint32_t)(n_tiles - 1) * (uint32_t)TILE_BYTES, s_vbits = (uint32_t)(uintptr_t)vbits;
+#if NNOP_DUO_STAMP
+    f32x8 profv = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#endif
 #if NNOP_DUO_PRIO == 2
     if (grp) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -390,13 +404,16 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         dbg[8] = (uint64_t)n_tiles;
         dbg[9] = stamp[2];
         dbg[10] = stamp[2];
-        for (int i = 0; i < 5; ++i) dbg[11 + i] = (uint64_t)sstate[i];     // cycles in M, barrier, V, DMA wait, barrier (wave 0)
+        for (int i = 0; i < 5; ++i) dbg[11 + i] = (uint64_t)__float_as_uint(profv[i]);     // cycles in M, barrier, V, DMA wait, barrier (wave 0)
     }
     if (tid == 256) {                                         // the same five of wave 4 (key group 1), in the block's second row
         uint64_t* dbg = reinterpret_cast<uint64_t*>((T*)p.o + ((size_t)bh * p.QL + q0w + 1) * E);
-        for (int i = 0; i < 5; ++i) dbg[i] = (uint64_t)sstate[i];
+        for (int i = 0; i < 5; ++i) dbg[i] = (uint64_t)__float_as_uint(profv[i]);
     }
 #endif
+    // the next block's prologue overwrites the rings / the exchange buffer / the validity words: every wave is done with them
+    if (pstep + 1 < n_steps_pers) __syncthreads();
+    }   // blocks of this workgroup
 }
 
 }  // namespace nnop

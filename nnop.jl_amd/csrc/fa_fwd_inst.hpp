@@ -86,6 +86,29 @@ static int launch_fwd_split(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
+// Persistent form of the masked-mode kernels (fa_fwd_w64.hpp, fa_fwd_duo.hpp): 256 workgroups that each walk `persist` blocks of a
+// static, balanced list instead of one workgroup per block -- on a 256-CU device, when the list divides: (batch x q-head) columns in
+// eighths (one per XCD), a power-of-two number of q-blocks per column, whole steps of 32 blocks per XCD, and more than one step.
+// Fills p.persist / p.persist_hx and the grid when the form applies.
+static inline void fwd_persist_plan(const nnop_fa_desc& d, const FwdArgs& a, FwdParams& p, long long& grid) {
+    const long long bh = (long long)d.batch * d.qh;
+    const int n = p.n_qblk;
+    const long long per_xcd = (bh / 8) * n;
+    // (auto: under a causal mask without key padding -- there the static list balances exactly and measured +3..4 % at E = 128
+    // L 8192-16384, +23 % at E = 64 L4096 H16 B4; equal-work blocks gain nothing (+-0.3 %), and per-batch key lengths make a
+    // static list 15 % SLOWER than the dispatcher's dynamic order: C4)
+    const int knob = tune_get(kTuneFwdPersist);
+    // per-batch key lengths WITHOUT a causal mask: balanced as well once every XCD takes an eighth of the heads of every batch
+    const int hx = d.qh % 8 == 0 ? d.qh / 8 : 0;
+    const bool pays = (d.causal && !a.kpad) || (!d.causal && a.kpad && hx > 0);
+    if ((knob == 1 || (knob < 0 && pays)) && device_cu_count() == 256 && bh % 8 == 0 && (n & (n - 1)) == 0 &&
+        per_xcd % 32 == 0 && per_xcd / 32 >= 2 && per_xcd / 32 <= (1 << 24)) {
+        p.persist = (int)(per_xcd / 32);
+        p.persist_hx = hx;
+        grid = 256;
+    }
+}
+
 // 64-rows-per-wave form (fa_fwd_w64.hpp): 4 waves x 64 rows, 16-bit types, E = 64 / 128, plain and masked modes
 template <typename T, int E, int MODE, bool PRE>
 static int launch_fwd_w64(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
@@ -106,28 +129,8 @@ static int launch_fwd_w64(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     p.n_wg = (int)n_wg;
     p.scale = (float)(1.0 / sqrt((double)E));
     if (n_wg * (E / EV) > 0x7fffffffLL) return NNOP_ERR_SHAPE;
-    // Persistent form (fa_fwd_w64.hpp): 256 workgroups that each walk `persist` blocks of a static, balanced list instead of one
-    // workgroup per block -- on a 256-CU device, when the list divides: (batch x q-head) columns in eighths (one per XCD), a power-
-    // of-two number of q-blocks per column, whole steps of 32 blocks per XCD, and more than one step.
     long long grid = n_wg * (E / EV);
-    if constexpr (EV == E && MODE == 1) {
-        const long long bh = (long long)d.batch * d.qh;
-        const int n = p.n_qblk;
-        const long long per_xcd = (bh / 8) * n;
-        // (auto: under a causal mask without key padding -- there the static list balances exactly and measured +3..4 % at E = 128
-        // L 8192-16384, +23 % at E = 64 L4096 H16 B4; equal-work blocks gain nothing (+-0.3 %), and per-batch key lengths make a
-        // static list 15 % SLOWER than the dispatcher's dynamic order: C4)
-        const int knob = tune_get(kTuneFwdPersist);
-        // per-batch key lengths WITHOUT a causal mask: balanced as well once every XCD takes an eighth of the heads of every batch
-        const int hx = d.qh % 8 == 0 ? d.qh / 8 : 0;
-        const bool pays = (d.causal && !a.kpad) || (!d.causal && a.kpad && hx > 0);
-        if ((knob == 1 || (knob < 0 && pays)) && device_cu_count() == 256 && bh % 8 == 0 && (n & (n - 1)) == 0 &&
-            per_xcd % 32 == 0 && per_xcd / 32 >= 2 && per_xcd / 32 <= (1 << 24)) {
-            p.persist = (int)(per_xcd / 32);
-            p.persist_hx = hx;
-            grid = 256;
-        }
-    }
+    if constexpr (EV == E && MODE == 1) fwd_persist_plan(d, a, p, grid);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, p);
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
@@ -150,7 +153,9 @@ static int launch_fwd_duo(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.n_wg = (int)n_wg;
     p.scale = (float)(1.0 / sqrt((double)E));
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), lds, s, p);
+    long long grid = n_wg;
+    if constexpr (MODE == 1) fwd_persist_plan(d, a, p, grid);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, p);
     return hipGetLastError() == hipSuccess ? NNOP_OK : NNOP_ERR_HIP;
 }
 
@@ -193,11 +198,15 @@ static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
         const bool masked = mode == 1;
         const bool pays = E == 128 ? (d.kl >= 256 && (wg256 >= 160 || (masked && wg256 >= 64)))
                                    : (masked ? (d.kl >= 512 && wg256 >= 128) : (d.kl >= 256 && wg256 >= 64));
-        // E = 64, exact scale: two waves per SIMD in alternating phases (fa_fwd_duo.hpp).  Knob kTuneFwdDuo: 0 never, 1 wherever
-        // instantiated, auto = off for now.
+        // E = 64, exact scale: two waves per SIMD in alternating matrix / vector phases (fa_fwd_duo.hpp).  Measured against the
+        // one-wave form on one box (tools/duo_check.py, profiles/r04/duo_sweep.log): 10-22 % faster from KL = 1024 up in plain mode at
+        // every grid size (32 .. 4096 workgroups), 3-20 % faster in masked mode from KL = 2048 (from KL = 1024 with >= 128
+        // workgroups); slower below (KL = 512: +10..19 %: the prologue holds three tiles and the epilogue merges two key groups).
+        // Knob kTuneFwdDuo: 0 never, 1 wherever instantiated, auto = this rule.
         if (E == 64 && fits && tune_get(kTuneFwdExactScale) != 0) {
             const int duo = tune_get(kTuneFwdDuo);
-            if (duo == 1) return kFormDuo;
+            const bool duo_pays = masked ? (d.kl >= 2048 || (d.kl >= 1024 && wg256 >= 128)) : d.kl >= 1024;
+            if (duo == 1 || (duo < 0 && w64 != 1 && duo_pays)) return kFormDuo;
         }
         if (fits && (w64 == 1 || (w64 < 0 && pays))) return kFormW64;
     }

@@ -32,7 +32,7 @@ for c in cfgs:
         mask = (torch.arange(KL)[None, :] < lens[:, None]).to(dev).contiguous()
     causal = mode == "causal"
     res, tm = {}, {}
-    for w in (0, 1):
+    for w in (0, 1):  # 0: the launcher without the duo form
         T("fwd_duo", w)
         o = torch.empty_like(q); ms = torch.empty(B, QH, L, dtype=DT[dt], device=dev); ls = torch.empty_like(ms)
         f = lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal, kpad_mask=mask)

@@ -21,10 +21,10 @@ Register map
              behind the loop), log2 units;  v[208:211] -m2 and m2 + 8, kept beside them
   v[196:203] k_voff0, k_voff1, v_voff (DMA source offsets), k_lane, v_lane (fragment read bases), qlim0, qlim1 (causal limit), 4 h
   v[204:207], v[212:223] temporaries
-  v[224:239] on entry: the scalar state, v[240:247] the two buffer descriptors (copied to scalar registers by the first instructions)
-  s[32:44]   t, H, n_live, kA, kB, kC (K ring slots of K(t), K(t+2), the free one), vA, vB, vC (V ring slots of V(t-2), V(t), free),
-             last_off, c2, causal_q0, vbits (LDS address of the validity words)
-  s[48:51]   K descriptor      s[52:55] V descriptor      s[56:67], s77 temporaries      s[68:76] profile builds
+  v[224:255] hipcc's (values that live across the loop: the epilogue's addresses); profile builds return five counters in v[224:228]
+  scalar operands (allocated by hipcc): t, H, n_live, kA, kB, kC (K ring slots of K(t), K(t+2), the free one), vA, vB, vC (V ring slots
+             of V(t-2), V(t), free), last_off, c2, causal_q0, vbits (LDS address of the validity words), the two buffer descriptors
+  s[56:67]   temporaries      s[68:76] profile builds
 
 The loop (per wave; group g = wave / 4 owns the kv tiles t = g mod 2; rings of 4 slots, tile t in slot t % 4):
   M(t)  matrix phase   row sums of P(t-2) (8 MFMAs 16x16x32: register operands, they cover the latency of the first fragment reads) |
@@ -51,7 +51,7 @@ L = lambda z: 96 + 4 * z
 SEL = 104
 KA = lambda ks: 107 + ks            # ks = 1..3 -> v108..v110
 S = lambda z, kb: 112 + 32 * z + 16 * kb
-FR = lambda i: 176 + 4 * i
+FR = lambda i: 176 + 4 * i if i < 4 else 224 + 4 * (i - 4)
 M2 = lambda z: 192 + z
 MT = lambda z: 194 + z
 KVO = lambda j: 196 + j
@@ -64,16 +64,15 @@ NM = lambda z: 208 + z               # -m2, or 0 while m2 = -inf            } ke
 THR = lambda z: 210 + z              # m2 + 8: the rescale threshold        }
 T0 = 212                             # v212..v223: temporaries
 PW = lambda kk, z: S(z, kk >> 1) + 8 * (kk & 1)         # P^T operand words of 16-key step kk: in place of the logits
-# scalars
-ST, SH, SNLIVE, SKA, SKB, SKC, SVA, SVB, SVC, SLAST, SC2, SCQ0, SVBITS = range(32, 45)
-N_STATE = 13
-KRS, VRS = "s[48:51]", "s[52:55]"
+# scalars: operands of the statement, allocated by hipcc (names in fa_fwd_duo.hpp's operand list)
+ST, SH, SNLIVE, SKA, SKB, SKC, SVA, SVB, SVC, SLAST, SC2, SCQ0, SVBITS = ("%[st]", "%[sh]", "%[snlive]", "%[ska]", "%[skb]", "%[skc]", "%[sva]",
+                                                                          "%[svb]", "%[svc]", "%[slast]", "%[sc2]", "%[scq0]", "%[svbits]")
+KRS, VRS = "%[krs]", "%[vrs]"
 SQK, SPV, SA, SB, SKOFF, SVOFF = 56, 57, 58, 59, 60, 61
 SVAL = "s[62:63]"
 SM = "s[64:65]"
 SNEED = 77
 
-PF = 3                               # fragments read ahead
 KS, KB, EB, NKF, NVF = 4, 2, 2, 8, 8
 NJK, NJV = 2, 2
 TILE_SHIFT = 13                      # one 64-key tile of E = 64 16-bit elements = 8 KiB
@@ -86,6 +85,10 @@ TILE_SHIFT = 13                      # one 64-key tile of E = 64 16-bit elements
 DMA_AT = os.environ.get("NNOP_DUO_GEN_DMA", "mtail")
 SLOTS = 2 if DMA_AT == "v" else 3
 
+ALIGN = os.environ.get("NNOP_DUO_GEN_ALIGN", "")          # experiment: "8" = .p2align 8 in front of the loop, "8+4" = the same + 4 bytes
+RING = int(os.environ.get("NNOP_DUO_GEN_RING", "4"))      # fragment ring slots (4 registers each): v[176:191] (+ v[224:...] beyond 4)
+PF = int(os.environ.get("NNOP_DUO_GEN_PF", "3"))          # fragments read ahead (< RING)
+
 # timing-only ablations (results WRONG by construction; never committed): NNOP_DUO_GEN_ABL bit mask
 #   1 no LDS-DMA in the loop   2 no row-max fillers   4 no exp / fma / convert in the vector phase   8 no MFMAs and no fragment reads
 ABL = int(os.environ.get("NNOP_DUO_GEN_ABL", "0"))
@@ -96,7 +99,7 @@ def vr(base, n=1):
 
 
 def sr(i):
-    return f"s{i}"
+    return i if isinstance(i, str) else f"s{i}"
 
 
 def v_rowmax():
@@ -180,7 +183,7 @@ def m_phase(qk, pv, masked):
         if p >= len(stream):
             return
         kind, idx = stream[p]
-        slot = FR(p % 4)
+        slot = FR(p % RING)
         if kind == "V":
             kk, eb = divmod(idx, EB)
             out.append(f"ds_read_b64_tr_b16 {vr(slot, 2)}, {vr(VIMG)} offset:{(8 * kk + eb) * 256}")
@@ -213,7 +216,7 @@ def m_phase(qk, pv, masked):
     for p, (kind, idx) in enumerate(stream):
         reads(p + PF)
         out.append(f"s_waitcnt lgkmcnt({lds_issued - 1 - last_read[p]})")
-        slot = FR(p % 4)
+        slot = FR(p % RING)
         if kind == "V":
             kk, eb = divmod(idx, EB)
             for z in range(2):
@@ -308,13 +311,12 @@ def tick(acc):
 def loop(masked, prof=False):
     """half-steps h = 0 .. n_tiles + 1, one barrier each; group g runs M(t) at h = t for t = g (mod 2) and V(t) at h = t + 1; PV(t)
     happens in M(t + 2).  (Group 1's idle half-step 0 is a barrier in front of this statement.)"""
-    # the scalar state arrives in vector registers (a 16-register SGPR tuple as an asm operand does not survive hipcc's copy
-    # legalisation: "illegal VGPR to SGPR copy")
-    out = [f"v_readfirstlane_b32 s{32 + i}, v{224 + i}" for i in range(N_STATE)]
-    out += [f"v_readfirstlane_b32 s{48 + i}, v{240 + i}" for i in range(8)]
+    out = []
     out += [f"v_mov_b32 {vr(NM(z))}, 0" for z in range(2)] + [f"v_mov_b32 {vr(THR(z))}, 0xff800000" for z in range(2)]     # m2 = -inf
     if prof:                         # s71..s75: cycles in M, at the barrier behind it, in V, in the DMA wait, at the barrier behind that
         out += ["s_memtime s[68:69]", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s70, s68"] + [f"s_mov_b32 s{a}, 0" for a in range(71, 76)]
+    if ALIGN:
+        out += [".p2align 8"] + (["s_nop 0"] if ALIGN.endswith("+4") else [])
     out += ["L_loop_%=:"]
     # qk = t < n_live;  pv = t >= 2 && t - 2 < n_live
     out += [f"s_cmp_lt_i32 {sr(ST)}, {sr(SNLIVE)}", f"s_cselect_b32 {sr(SQK)}, 1, 0",
