@@ -207,17 +207,15 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     // ---- prologue: the group's first tiles in flight -- K(g), K(g+2), V(g) (the loop's first batch is K(g+4), V(g+2)) -----------------
     static_for<NJK>([&](auto jc) { issue_k_piece(tile_off(grp), kA, jc); });
     const float c2 = p.scale * kLog2e;
-    f32x16 qf[2];                                             // the 4 fragments (16-deep steps of E) of query block z, as one tuple
+    // Q fragments: asm loads (invisible to hipcc's wait-count bookkeeping, like the LDS-DMA around them), valid behind the counted wait
+    // below, which takes them as operands
+    f32x4 qw[2][KS];
 #pragma unroll
     for (int z = 0; z < 2; ++z) {
         const int qc = qi[z] < p.QL ? qi[z] : p.QL - 1;
         const T* qrow = qp + (size_t)qc * E;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(qrow + 16 * ks + 8 * h);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) qf[z][4 * ks + i] = w[i];
-        }
+        for (int ks = 0; ks < KS; ++ks) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qw[z][ks]) : "v"(qrow + 16 * ks + 8 * h) : "memory");
     }
     f32x16 oacc[2][EB];
     f32x4 lacc[2];                                            // row sums: registers 0 / 1 of lanes 0..15 = queries lane, lane + 16 (SumMfma)
@@ -250,8 +248,19 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     });
     const uint32_t k_lane = (uint32_t)(r * KImg::kRowBytes + ((KImg::xor_of(r) ^ h) << 4)) - wave_off_k;
     const uint32_t v_lane = (uint32_t)VImg::lane_base(lane) - wave_off_v;
-    // K(grp) and Q landed (every wave's pieces: barrier).  The Q fragments pass through the statement.
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : "+v"(qf[0]), "+v"(qf[1]) :: "memory");
+    // K(grp) and Q landed (every wave's pieces: barrier); K(grp+2) and V(grp) -- the NJK + NJV pieces issued last -- stay in flight: the
+    // loop's first counted wait (end of V(grp)) retires them, in time for M(grp+2).  The Q fragments pass through the statement.
+    static_assert(KS == 4 && NJK + NJV == 4, "operand list / vmcnt literal below");
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier"
+                 : "+v"(qw[0][0]), "+v"(qw[0][1]), "+v"(qw[0][2]), "+v"(qw[0][3]), "+v"(qw[1][0]), "+v"(qw[1][1]), "+v"(qw[1][2]), "+v"(qw[1][3])
+                 :: "memory");
+    f32x16 qf[2];                                             // the 4 fragments (16-deep steps of E) of query block z, as one tuple
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qf[z][4 * ks + i] = qw[z][ks][i];
 #if NNOP_DUO_STAMP
     stamp[2] = __builtin_amdgcn_s_memtime();
     stamp[3] = __builtin_amdgcn_s_memrealtime();

@@ -358,6 +358,83 @@ def loop(masked, prof=False):
     return out
 
 
+def check_stream(lines):
+    """Static audit of one generated loop (hipcc pads nothing inside an asm statement, so the streams carry their own waits):
+      1. every fragment an MFMA reads has been requested and WAITED for (LDS returns in order: s_waitcnt lgkmcnt(n) retires all but
+         the n youngest requests), and no LDS read overwrites a fragment register that is still waiting to be consumed;
+      2. a transcendental's result is not read by the very next instruction (one wait state, gfx940+);
+      3. v_permlane32_swap is not directly behind a VALU write of its operands (two wait states); s_mov m0 -> LDS-DMA has its s_nop;
+      4. behind the barrier that closes a matrix phase, >= 16 vector instructions (>= 64 cycles) precede the first read of a score
+         register of key block 1 -- the last QK^T MFMAs were issued right in front of that barrier (key block 0 was finished 8 MFMAs
+         earlier) -- unless explicit idle cycles do the same;
+      5. the P^T words an MFMA reads were all written (v_cvt_pk) in the vector phase before (structural: same registers as S)."""
+    import re
+    reg_re = re.compile(r"v\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+    def regs(tok):
+        out = set()
+        for m in reg_re.finditer(tok):
+            if m.group(1):
+                out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+            else:
+                out.add(int(m.group(3)))
+        return out
+
+    pending = []                     # outstanding LDS requests, oldest first: sets of destination registers
+    prev = ""
+    since_barrier, idle = None, 0
+    for ln in lines:
+        op = ln.split()[0] if ln and not ln.endswith(":") and not ln.startswith("@") else ""
+        args = ln[len(op):].split(",") if op else []
+        if ln.endswith(":") or op in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1"):
+            # control flow: every path into a label has drained its requests in these streams (phases end with lgkmcnt(0) or MFMAs that
+            # consumed everything); keep the model simple and conservative
+            if op == "":
+                pending = [] if not ln.startswith("L_mdone") else pending
+        if op.startswith("ds_read") or op.startswith("ds_bpermute"):
+            dst = regs(args[0])
+            for d in pending:
+                assert not (d & dst), f"LDS read overwrites a pending fragment: {ln}"
+            pending.append(dst)
+        elif op == "s_memtime":
+            pending.append(set())
+        elif op == "s_waitcnt" and "lgkmcnt" in ln:
+            n = int(re.search(r"lgkmcnt\((\d+)\)", ln).group(1))
+            pending = pending[len(pending) - n:] if n else []
+        elif op.startswith("v_mfma"):
+            src = regs(args[1]) | regs(args[2])
+            for d in pending:
+                assert not (d & src), f"MFMA reads a fragment that was not waited for: {ln}"
+        elif op.startswith("v_") or op.startswith("buffer_"):
+            src = set().union(*[regs(a) for a in args[1:]]) if len(args) > 1 else set()
+            for d in pending:
+                assert not (d & src), f"vector instruction reads an LDS result that was not waited for: {ln}"
+        if prev.startswith("v_exp_f32") and op.startswith("v_") and not op.startswith("v_exp"):
+            assert not (regs(prev.split(",")[0]) & set().union(*[regs(a) for a in args[1:]])), f"transcendental result read without a wait state: {ln}"
+        if op == "v_permlane32_swap_b32":
+            assert prev.startswith("s_nop") or prev.startswith("v_permlane32_swap"), f"v_permlane32_swap directly behind a vector instruction: {ln}"
+        if op.startswith("buffer_load") and prev.startswith("s_mov_b32 m0"):
+            assert False, f"LDS-DMA directly behind the M0 write: {ln}"
+        # rule 4
+        if op == "s_barrier":
+            since_barrier, idle = 0, 0
+        elif since_barrier is not None and op:
+            if op == "s_nop":
+                idle += int(ln.split()[1]) + 1
+            elif op.startswith("v_") and not op.startswith("v_mfma"):
+                kb1 = set(range(S(0, 1), S(0, 1) + 16)) | set(range(S(1, 1), S(1, 1) + 16))
+                if set().union(*[regs(a) for a in args[1:]]) & kb1:
+                    assert 4 * since_barrier + idle >= 64, f"score registers of key block 1 read {since_barrier} instructions behind the barrier: {ln}"
+                    since_barrier = None
+                else:
+                    since_barrier += 1
+            elif op.startswith("v_mfma"):
+                since_barrier = None
+        if op:
+            prev = ln
+    return True
+
+
 def as_macro(name, lines):
     body = " \\\n".join(f'    "{ln}\\n\\t"' for ln in lines)
     text = f"#define {name}(TS, MP1, MP0, VP1, VP0) \\\n{body}\n".replace("@T@", '" TS "')
@@ -371,6 +448,8 @@ def render():
              "// The phase loop of fa_fwd_duo.hpp with fixed physical registers (register map: the generator's header).\n"
              "// TS: the element type's mnemonic suffix (\"bf16\" / \"f16\").\n"
              f"#define NNOP_DUO_SLOTS_PER_GROUP {SLOTS}      // ring slots per key group and ring (where the DMA batch is issued decides)\n"]
+    for masked in (False, True):
+        check_stream(loop(masked))
     parts.append(as_macro("NNOP_DUO_LOOP_PLAIN", loop(False)))
     parts.append(as_macro("NNOP_DUO_LOOP_MASKED", loop(True)))
     parts.append("// profile builds (make DEV=1 VAR=-DNNOP_DUO_STAMP=1): the same loops with s_memtime ticks; the five accumulators leave in v[224:228]\n"
