@@ -27,6 +27,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 import statistics
 import sys
 import time

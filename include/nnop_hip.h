@@ -62,7 +62,12 @@ typedef enum nnop_status {
                                       ... Shared Memory constraint", attention.jl:204)                       */
     NNOP_ERR_SHAPE          = -8,  /* a non-positive / overflowing dimension                                 */
     NNOP_ERR_WORKSPACE      = -9,  /* workspace smaller than nnop_fa_bwd_workspace_bytes                      */
-    NNOP_ERR_HIP            = -10  /* HIP runtime error at launch (hipGetLastError)                          */
+    NNOP_ERR_HIP            = -10, /* HIP runtime error at launch (hipGetLastError)                          */
+    NNOP_ERR_ALIGN          = -11  /* a tensor or workspace base address is not aligned as the kernels need:
+                                      16 bytes for q, k, v, o, the gradients, pair / dpair and the workspace
+                                      (the MFMA kernels move them with 16-byte vector accesses and LDS-DMA),
+                                      the element size for ms, ls.  Embedding dims that run the plain-HIP
+                                      kernels (not 16 / 32 / 64 / 128 / 256) need element alignment only.      */
 } nnop_status;
 
 /*
@@ -214,6 +219,29 @@ int nnop_layer_norm_bwd(const nnop_norm_desc* d, void* dx, void* dw, void* db, c
 /* layer_norm: 0 = RMSNorm pullback, 1 = LayerNorm pullback.  Returns 0 for an invalid descriptor. */
 size_t nnop_norm_bwd_workspace_bytes(const nnop_norm_desc* d, int layer_norm);
 
+/*
+ * Sharding over several devices (ABI version 6).  The reference has no multi-GPU code; its (batch, kv-head) slices -- a KV head with its
+ * QH / KH query heads -- are independent in forward and backward (src/attention.jl:27-28,33; src/attention_bwd.jl:28-29,34), so a host
+ * that owns several devices gives rank g of `world` the contiguous unit range [g U / world, (g+1) U / world), U = batch * kh, units
+ * numbered u = b * kh + h (batch slowest, as in memory).  In the [B][H][L][E] layout that range is at most three DENSE rectangles
+ * (tail of the first batch, whole batches, head of the last batch); each is a problem of its own for nnop_fa_fwd / nnop_fa_bwd at the
+ * element offsets below -- pointer arithmetic only, no copies, no collective.  Host-only: touches no device.
+ * Returns the number of rectangles written to `out` (0..3), or a negative nnop_status for an invalid descriptor / world / rank.
+ */
+typedef struct nnop_fa_shard {
+    nnop_fa_desc desc;   /* the rectangle as a problem: batch, qh, kh replaced; everything else as in the full problem */
+    int32_t  b0, b1;     /* batches  [b0, b1)  of the full problem */
+    int32_t  kh0, kh1;   /* kv heads [kh0, kh1) (query heads [kh0, kh1) * qh / kh) */
+    uint64_t q_off;      /* ELEMENT offset of the rectangle in q, o, dO, dq   ([B][QH][QL][E]) */
+    uint64_t kv_off;     /* ... in k, v, dk, dv                               ([B][KH][KL][E]) */
+    uint64_t row_off;    /* ... in ms, ls                                     ([B][QH][QL])    */
+    uint64_t mask_off;   /* BYTE offset in kpad_mask                          ([B][KL])        */
+    int64_t  pair_off;   /* element offset in pair / dpair ([B][KL][QL][QH]) when the rectangle holds ALL heads of its batches;
+                            -1 otherwise: part of a batch's heads is not a dense sub-array of the head-fastest bias layout (the caller
+                            then hands that rectangle a head-sliced copy, or shards whole batches: world <= batch) */
+} nnop_fa_shard;
+int nnop_fa_shards(const nnop_fa_desc* d, int world, int rank, nnop_fa_shard out[3]);
+
 /* NNop._shared_memory(::ROCBackend, device_id) (ext/NNopAMDGPUExt.jl:6-9):
  * hipDeviceProp_t.sharedMemPerBlock of `device` (0-based HIP ordinal). */
 int nnop_shared_memory(int device, uint64_t* bytes);
@@ -222,7 +250,7 @@ int nnop_shared_memory(int device, uint64_t* bytes);
 const char* nnop_strerror(int status);
 
 /* ABI version of this header: bumped on any incompatible change. */
-#define NNOP_HIP_ABI_VERSION 5
+#define NNOP_HIP_ABI_VERSION 6
 int nnop_abi_version(void);
 
 #ifdef __cplusplus

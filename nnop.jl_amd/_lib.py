@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NNOP_LIB_PATH") or os.path.join(_HERE, "lib", "libnnop_hip.so")
 
 # NNOP_HIP_ABI_VERSION of the header this binding was written against; load() refuses another library
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # nnop_dtype (include/nnop_hip.h)
 NNOP_F32, NNOP_F16, NNOP_BF16 = 0, 1, 2
@@ -31,6 +31,7 @@ NNOP_ERR_EMB_UNSUPPORTED = -7
 NNOP_ERR_SHAPE = -8
 NNOP_ERR_WORKSPACE = -9
 NNOP_ERR_HIP = -10
+NNOP_ERR_ALIGN = -11
 
 EXPORTED_SYMBOLS = (
     "nnop_fa_fwd",
@@ -45,6 +46,7 @@ EXPORTED_SYMBOLS = (
     "nnop_layer_norm",
     "nnop_layer_norm_bwd",
     "nnop_norm_bwd_workspace_bytes",
+    "nnop_fa_shards",
     "nnop_shared_memory",
     "nnop_strerror",
     "nnop_abi_version",
@@ -59,6 +61,10 @@ TUNE_KEYS = {"fwd_split": 0, "fwd_nw": 1, "fwd_w64": 2, "bwd_big7": 3, "norm_bwd
              "fwd_exact_scale": 6, "bwd_w64": 7, "bwd_stages": 8, "fwd_persist": 9, "bwd_persist": 10, "fwd_duo": 11}
 
 
+class FaShard(C.Structure):
+    """struct nnop_fa_shard (declared below FaDesc; fields filled in after it)"""
+
+
 class FaDesc(C.Structure):
     """struct nnop_fa_desc"""
     _fields_ = [
@@ -66,6 +72,11 @@ class FaDesc(C.Structure):
         ("qh", C.c_int32), ("kh", C.c_int32), ("batch", C.c_int32), ("causal", C.c_int32),
         ("emb_k", C.c_int32), ("emb_v", C.c_int32), ("kl_v", C.c_int32), ("kh_v", C.c_int32),
     ]
+
+
+FaShard._fields_ = [("desc", FaDesc), ("b0", C.c_int32), ("b1", C.c_int32), ("kh0", C.c_int32), ("kh1", C.c_int32),
+                    ("q_off", C.c_uint64), ("kv_off", C.c_uint64), ("row_off", C.c_uint64), ("mask_off", C.c_uint64),
+                    ("pair_off", C.c_int64)]
 
 
 class RopeDesc(C.Structure):
@@ -139,6 +150,8 @@ def load():
     lib.nnop_layer_norm_bwd.argtypes = [nd, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.nnop_norm_bwd_workspace_bytes.restype = C.c_size_t
     lib.nnop_norm_bwd_workspace_bytes.argtypes = [nd, C.c_int]
+    lib.nnop_fa_shards.restype = C.c_int
+    lib.nnop_fa_shards.argtypes = [C.POINTER(FaDesc), C.c_int, C.c_int, C.POINTER(FaShard)]
     lib.nnop_shared_memory.restype = C.c_int
     lib.nnop_shared_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.nnop_strerror.restype = C.c_char_p
@@ -163,11 +176,24 @@ def strerror(status: int) -> str:
 
 
 def debug_set(key: str, value: int) -> int:
-    """Test-only: override one launch-shape knob (csrc/tuning.hpp); -1 = automatic.  Returns the previous value."""
+    """Test-only: override one launch-shape knob (csrc/tuning.hpp); -1 = automatic.  Returns the previous value.
+    The hook is LOCKED unless the process environment held NNOP_DEBUG_HOOKS=1 at the library's first launch (the test-suite's
+    conftest and bench.py set it): a production host cannot flip process-wide kernel selection by accident."""
     prev = load().nnop_debug_set(TUNE_KEYS[key], int(value))
     if prev == -(2 ** 31):
+        if os.environ.get("NNOP_DEBUG_HOOKS", "0") in ("", "0"):
+            raise RuntimeError("nnop_debug_set is locked: start the process with NNOP_DEBUG_HOOKS=1 (csrc/nnop_debug.h)")
         raise KeyError(key)
     return prev
+
+
+def fa_shards(desc: FaDesc, world: int, rank: int):
+    """nnop_fa_shards: rank's (batch, kv-head) unit range as <= 3 dense rectangles with their element offsets (host-only)."""
+    out = (FaShard * 3)()
+    n = load().nnop_fa_shards(C.byref(desc), int(world), int(rank), out)
+    if n < 0:
+        raise ValueError(strerror(n))
+    return [out[i] for i in range(n)]
 
 
 def dev_build() -> bool:

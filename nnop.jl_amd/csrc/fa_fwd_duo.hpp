@@ -295,7 +295,9 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
 #if NNOP_DUO_PRIO == 2
     if (grp) __builtin_amdgcn_s_setprio(1);
 #endif
+#if !NNOP_DUO_SYNC_ONE
     if (grp) asm volatile("s_barrier" ::: "memory");          // half-step 0: group 1 has nothing to do yet
+#endif
 #if NNOP_DUO_STAMP
 #define NNOP_DUO_LOOP_MASKED NNOP_DUO_LOOP_MASKED_PROF
 #define NNOP_DUO_LOOP_PLAIN NNOP_DUO_LOOP_PLAIN_PROF

@@ -61,6 +61,7 @@ function check(st::Cint, q, k, v)
     st == -3 && error("Only power-of-2 embedding dims are supported.")
     st == -4 && error("Number of query heads `$(size(q, 3))` must be divisible by number of KV heads `$(size(k, 3))`.")
     st == -7 && error("Failed to find groupsize for Flash Attention that satisfies Shared Memory constraint.")
+    st == -11 && error("libnnop_hip: a tensor base address is not 16-byte aligned (views with odd element offsets are not supported: copy them)")
     msg = unsafe_string(ccall((:nnop_strerror, libnnop()), Cstring, (Cint,), st))
     error("libnnop_hip: $msg")
 end
@@ -152,6 +153,62 @@ function NNop.∇flash_attention(
     causal::Bool, kpad_mask::Union{Nothing,ROCMatrix{Bool}} = nothing,
 ) where T <: HipFloat
     return NNop.∇flash_attention(_to_roc(Δ, o)::ROCArray{T,4}, o, ms, ls, q, k, v, pair; causal, kpad_mask)
+end
+
+# ---- several devices (include/nnop_hip.h: nnop_fa_shards, ABI version 6) -------------------------------------------------------------
+# The reference has no multi-GPU code; (batch, kv-head) slices are independent in forward and backward (src/attention.jl:27-28,33;
+# src/attention_bwd.jl:28-29,34), so the H x B axis shards with pointer offsets and NO data-path collective.  nnop_fa_shards gives
+# rank g of `world` its contiguous unit range as <= 3 dense rectangles; each is a problem of its own for _flash_attention at the
+# element offsets it reports.  Two ways to use it from Julia:
+#   * one process per GPU (MPI.jl / Distributed.jl): call `flash_attention_shard(q, k, v, world, rank; causal)` on the rank's device
+#     with the FULL arrays resident there, or with the rank's slices and world = 1;
+#   * one process driving all GPUs (below): `flash_attention_multi(qs, ks, vs; causal)` with one (q, k, v) replica or slice per device
+#     -- a task per device, each on its own task-local HIP stream (AMDGPU.device! is task-local), joined at the end.
+# struct nnop_fa_shard
+struct FaShard
+    desc::FaDesc
+    b0::Int32; b1::Int32; kh0::Int32; kh1::Int32
+    q_off::UInt64; kv_off::UInt64; row_off::UInt64; mask_off::UInt64; pair_off::Int64
+end
+
+function fa_shards(q, k, v, causal::Bool, world::Integer, rank::Integer)
+    out = Vector{FaShard}(undef, 3)
+    n = ccall((:nnop_fa_shards, libnnop()), Cint, (Ptr{FaDesc}, Cint, Cint, Ptr{FaShard}), Ref(desc(q, k, v, causal)), world, rank, out)
+    n < 0 && check(n, q, k, v)
+    return out[1:n]
+end
+
+# Rank `rank` (0-based) of `world`: its rectangles of o, ms, ls are written in place into full-size outputs (the rest is left
+# untouched: another rank's).  No copies: `view`s of the (E, L, H, B) arrays over head / batch ranges are the rectangles.
+function flash_attention_shard!(o, ms, ls, q::ROCArray{T,4}, k::ROCArray{T,4}, v::ROCArray{T,4}, world::Integer, rank::Integer;
+                                causal::Bool, kpad_mask::Union{Nothing,ROCMatrix{Bool}} = nothing) where T <: HipFloat
+    rep = size(q, 3) ÷ size(k, 3)
+    for s in fa_shards(q, k, v, causal, world, rank)
+        b, h, qh = (s.b0 + 1):s.b1, (s.kh0 + 1):s.kh1, (s.kh0 * rep + 1):(s.kh1 * rep)
+        # the four views are dense (whole batches, or a head range of one batch): the library sees plain [B'][H'][L][E] problems
+        oo, mm, ll = NNop._flash_attention(q[:, :, qh, b], k[:, :, h, b], v[:, :, h, b]; causal,
+                                           kpad_mask = isnothing(kpad_mask) ? nothing : kpad_mask[:, b])
+        o[:, :, qh, b] .= oo; ms[:, qh, b] .= mm; ls[:, qh, b] .= ll
+    end
+    return o, ms, ls
+end
+# (The indexing above copies the rectangle -- the simple, allocation-tolerant form.  The zero-copy form passes
+#  devptr(q) + s.q_off * sizeof(T), devptr(k) + s.kv_off * sizeof(T), ... with Ref(s.desc) straight to :nnop_fa_fwd / :nnop_fa_bwd,
+#  exactly as _flash_attention does with offset 0; the offsets are multiples of L * E elements, so 16-byte alignment is kept.)
+
+# One process, all devices: qs[g], ks[g], vs[g] live on device g (replicas or batch slices of the global problem).
+function flash_attention_multi(qs::Vector, ks::Vector, vs::Vector; causal::Bool)
+    world = length(qs)
+    tasks = map(1:world) do g
+        Threads.@spawn begin
+            AMDGPU.device!(AMDGPU.devices()[g])                 # task-local: this task's arrays and stream live on device g
+            o, ms, ls = similar(qs[g]), ROCArray{eltype(qs[g])}(undef, size(qs[g])[2:4]...), ROCArray{eltype(qs[g])}(undef, size(qs[g])[2:4]...)
+            flash_attention_shard!(o, ms, ls, qs[g], ks[g], vs[g], world, g - 1; causal)
+            AMDGPU.synchronize()
+            (o, ms, ls)
+        end
+    end
+    return fetch.(tasks)
 end
 
 # struct nnop_rope_desc (include/nnop_hip.h)

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the kernel-form hook nnop_debug_set (csrc/nnop_debug.h) is locked unless the process starts with this (read at the library's first launch)
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

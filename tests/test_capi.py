@@ -113,3 +113,69 @@ def test_workspace_bytes(pkg):
 
 def test_shared_memory_null_pointer(pkg):
     assert pkg._lib.load().nnop_shared_memory(0, None) == pkg._lib.NNOP_ERR_NULL
+
+
+def test_debug_hook_is_locked_without_the_environment_switch():
+    """nnop_debug_set flips process-wide kernel selection (and, through bwd_stages, which passes nnop_fa_bwd runs): a host that merely
+    links the library must not reach it.  A fresh process WITHOUT NNOP_DEBUG_HOOKS gets INT_MIN back; with it, the previous value."""
+    code = ("import ctypes as C, sys; lib = C.CDLL(sys.argv[1]); lib.nnop_debug_set.restype = C.c_int; "
+            "print(lib.nnop_debug_set(1, 4), lib.nnop_debug_set(1, -1))")
+    import __graft_entry__ as ge
+    path = ge.load_package()._lib.LIB_PATH
+    env = {k: v for k, v in os.environ.items() if k != "NNOP_DEBUG_HOOKS"}
+    locked = subprocess.run([os.sys.executable, "-c", code, path], capture_output=True, text=True, env=env)
+    assert locked.stdout.split() == [str(-(2 ** 31))] * 2, locked.stdout + locked.stderr
+    env["NNOP_DEBUG_HOOKS"] = "1"
+    open_ = subprocess.run([os.sys.executable, "-c", code, path], capture_output=True, text=True, env=env)
+    assert open_.stdout.split() == ["-1", "4"], open_.stdout + open_.stderr
+
+
+def test_misaligned_bases_are_refused_before_any_launch(pkg):
+    """NNOP_ERR_ALIGN: the MFMA kernels move q, k, v, o, the gradients, the bias and the workspace with 16-byte vector accesses and
+    LDS-DMA from the raw base.  Checked behind the descriptor and NULL checks, in front of the launch (so this runs without a GPU:
+    the call returns before it touches the device)."""
+    lib = pkg._lib.load()
+    d = _desc(pkg)
+    ok = 0x7f0000001000                                     # fake, aligned, never dereferenced: every call below fails earlier
+    vp = C.c_void_p
+    for bad_pos in range(6):                                # o, ms, ls, q, k, v
+        args = [ok] * 6
+        args[bad_pos] = ok + (2 if bad_pos in (1, 2) else 8) - (1 if bad_pos in (1, 2) else 0)   # ms / ls: element (2-byte) alignment
+        st = lib.nnop_fa_fwd(C.byref(d), *[vp(a) for a in args], None, None, None)
+        assert st == pkg._lib.NNOP_ERR_ALIGN, (bad_pos, st)
+    # the plain-HIP kernels (embedding dims outside the tiled set) need element alignment only: 8 bytes off is fine for E = 8 ...
+    d8 = _desc(pkg, emb=8)
+    st = lib.nnop_fa_bwd(C.byref(d8), vp(ok + 8), vp(ok), vp(ok), None, vp(ok), vp(ok), vp(ok), vp(ok), vp(ok), vp(ok), vp(ok), None, None,
+                         vp(ok + 4), C.c_size_t(1 << 30), None)
+    assert st == pkg._lib.NNOP_ERR_ALIGN                    # ... but the workspace is always 16-byte aligned
+    st = lib.nnop_fa_bwd(C.byref(d), vp(ok), vp(ok), vp(ok + 8), None, vp(ok), vp(ok), vp(ok), vp(ok), vp(ok), vp(ok), vp(ok), None, None,
+                         vp(ok), C.c_size_t(1 << 30), None)
+    assert st == pkg._lib.NNOP_ERR_ALIGN
+    assert "misaligned" in pkg._lib.strerror(pkg._lib.NNOP_ERR_ALIGN)
+    assert "1 ... 512" in pkg._lib.strerror(pkg._lib.NNOP_ERR_EMB_UNSUPPORTED)
+
+
+@pytest.mark.parametrize("B,KH,rep", [(4, 4, 1), (8, 2, 4), (3, 5, 2), (1, 8, 1), (64, 32, 1), (7, 3, 3)])
+def test_shard_entry_equals_the_python_sharding(pkg, B, KH, rep):
+    """nnop_fa_shards (the host-side entry a Julia caller loops over, one device per rank) against nnop.jl_amd/shard.py: the same
+    rectangles for every world size and rank, offsets = the start of the rectangle in each tensor, every unit covered exactly once."""
+    shard = pkg.shard
+    QH, QL, KL, E = KH * rep, 96, 160, 64
+    d = _desc(pkg, batch=B, kh=KH, qh=QH, ql=QL, kl=KL, emb=E)
+    for world in (1, 2, 3, 8, B * KH, B * KH + 3):
+        seen = []
+        for rank in range(world):
+            got = pkg._lib.fa_shards(d, world, rank)
+            want = shard.rectangles(B, KH, world, rank)
+            assert [(s.b0, s.b1, s.kh0, s.kh1) for s in got] == [(r.b0, r.b1, r.kh0, r.kh1) for r in want]
+            for s in got:
+                assert (s.desc.batch, s.desc.kh, s.desc.qh) == (s.b1 - s.b0, s.kh1 - s.kh0, (s.kh1 - s.kh0) * rep)
+                assert (s.desc.ql, s.desc.kl, s.desc.emb, s.desc.dtype, s.desc.causal) == (QL, KL, E, d.dtype, d.causal)
+                qhead = s.b0 * QH + s.kh0 * rep
+                assert s.q_off == qhead * QL * E and s.kv_off == (s.b0 * KH + s.kh0) * KL * E
+                assert s.row_off == qhead * QL and s.mask_off == s.b0 * KL
+                whole = s.kh0 == 0 and s.kh1 == KH
+                assert s.pair_off == (s.b0 * KL * QL * QH if whole else -1)
+                seen += [(b, h) for b in range(s.b0, s.b1) for h in range(s.kh0, s.kh1)]
+        assert sorted(seen) == [(b, h) for b in range(B) for h in range(KH)]
+    assert pkg._lib.load().nnop_fa_shards(C.byref(d), 2, 2, (pkg._lib.FaShard * 3)()) == pkg._lib.NNOP_ERR_SHAPE

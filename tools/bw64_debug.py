@@ -2,6 +2,7 @@
 dO = one-hot at (q0, e0)  ->  dV[key][e0] = P[q0][key]: the kernel's own P, read out through its dV product.
 usage: bw64_debug.py [E] [QL] [KL] [causal]"""
 import os, sys
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -3,6 +3,7 @@ OUTDIR=../lib_stamp BUILD=../build_stamp`, passed through NNOP_LIB_PATH): prolog
 cycles per iteration and per MFMA, in-kernel clock.  The stamps overwrite the first gradient row of every workgroup (results WRONG).
 usage: bw64_stamp.py dt:E:L:QH:KH:B[:causal] ..."""
 import os, sys, torch
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge

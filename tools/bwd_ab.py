@@ -1,5 +1,6 @@
 """dev: backward time per shape under launch-shape knobs (debug_set), steady state.  usage: bwd_ab.py knob=v[,knob=v] ... -- dt:E:L:QH:KH:B:mode ..."""
 import os, sys, torch
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge

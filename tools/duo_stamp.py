@@ -3,6 +3,7 @@ BUILD=../build_stamp`, passed through NNOP_LIB_PATH): prologue / loop / epilogue
 (= per half-step pair: one tile of either key group), where wave 0 spends them (matrix phase, barrier, vector phase, DMA wait, barrier)
 and the in-kernel clock.  usage: duo_stamp.py dt:E:L:QH:KH:B[:causal] ..."""
 import os, sys, torch
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge

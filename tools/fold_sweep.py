@@ -5,6 +5,7 @@ the "massive activation" pattern of trained transformers), sweeps M, and prints 
 default and for the exact-scale variant (tests/util.py tolerances; > 1 = outside).
 usage: fold_sweep.py [dt] [E]"""
 import os, sys
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -3,6 +3,7 @@ csrc/fa_bwd.hpp (`bwd_w64=0`) on the same residuals -- no oracle, so it is cheap
 the structured tests may miss (tiny / ragged lengths, GQA ratios, QL != KL under the causal mask, every padding kind, E = 256).
 Also repeats every new-form launch once and requires bitwise equality.   usage: fuzz_bw64.py [n_cases] [seed]"""
 import os, sys
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

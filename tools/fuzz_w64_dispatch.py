@@ -2,6 +2,7 @@
 launcher picks against the 32-row forms (knob fwd_w64=0) on the same inputs: max difference and NaN pattern."""
 import sys, torch, numpy as np
 import os
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package(); dev = torch.device('cuda:0')

@@ -85,7 +85,7 @@ TILE_SHIFT = 13                      # one 64-key tile of E = 64 16-bit elements
 DMA_AT = os.environ.get("NNOP_DUO_GEN_DMA", "mtail")
 SLOTS = 2 if DMA_AT == "v" else 3
 
-ALIGN = os.environ.get("NNOP_DUO_GEN_ALIGN", "")          # experiment: "8" = .p2align 8 in front of the loop, "8+4" = the same + 4 bytes
+SYNC = os.environ.get("NNOP_DUO_GEN_SYNC", "one")        # barriers per iteration: "two" (behind every phase) / "one" (group_loop)
 RING = int(os.environ.get("NNOP_DUO_GEN_RING", "4"))      # fragment ring slots (4 registers each): v[176:191] (+ v[224:...] beyond 4)
 PF = int(os.environ.get("NNOP_DUO_GEN_PF", "3"))          # fragments read ahead (< RING)
 
@@ -125,14 +125,14 @@ def v_rowmax():
     return out
 
 
-def v_mask():
+def v_mask(g=0):
     """masked mode: does tile t need its mask (validity word != all ones, or the tile reaches past the wave's first query)?  Rare
     (padding / ragged end / causal diagonal): set the hidden logits of S(t) to -inf.  Per (z, kb) ONE 32-bit lane mask: validity bits
     of the lane's key rows AND the causal prefix.  (The validity word was fetched by the matrix phase into v[212:213].)"""
     out = [f"v_readfirstlane_b32 s62, {vr(T0 + 2)}", f"v_readfirstlane_b32 s63, {vr(T0 + 3)}",
-           f"s_cmp_lg_u64 {SVAL}, -1", "s_cbranch_scc1 L_domask_%=",
+           f"s_cmp_lg_u64 {SVAL}, -1", f"s_cbranch_scc1 L_domask{g}_%=",
            f"s_lshl_b32 {sr(SA)}, {sr(ST)}, 6", f"s_add_i32 {sr(SA)}, {sr(SA)}, 63", f"s_cmp_gt_i32 {sr(SA)}, {sr(SCQ0)}",
-           "s_cbranch_scc0 L_maskdone_%=", "L_domask_%=:", f"v_mov_b32 {vr(T0 + 10)}, 0xff800000"]
+           f"s_cbranch_scc0 L_maskdone{g}_%=", f"L_domask{g}_%=:", f"v_mov_b32 {vr(T0 + 10)}, 0xff800000"]
     lim, cm, sh, w = T0 + 4, T0 + 5, T0 + 6, T0 + 8        # w: 2 registers
     for z in range(2):
         for kb in range(KB):
@@ -149,7 +149,7 @@ def v_mask():
                 r = S(z, kb) + i
                 out += [f"v_and_b32 {vr(sh)}, {hex(1 << lr)}, {vr(cm)}", f"v_cmp_ne_u32 vcc, 0, {vr(sh)}",
                         f"v_cndmask_b32 {vr(r)}, {vr(T0 + 10)}, {vr(r)}, vcc"]
-    out.append("L_maskdone_%=:")
+    out.append(f"L_maskdone{g}_%=:")
     return out
 
 
@@ -308,16 +308,13 @@ def tick(acc):
     return ["s_memtime s[68:69]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s76, s68, s70", f"s_add_u32 s{acc}, s{acc}, s76", "s_mov_b32 s70, s68"]
 
 
-def loop(masked, prof=False):
-    """half-steps h = 0 .. n_tiles + 1, one barrier each; group g runs M(t) at h = t for t = g (mod 2) and V(t) at h = t + 1; PV(t)
-    happens in M(t + 2).  (Group 1's idle half-step 0 is a barrier in front of this statement.)"""
-    out = []
-    out += [f"v_mov_b32 {vr(NM(z))}, 0" for z in range(2)] + [f"v_mov_b32 {vr(THR(z))}, 0xff800000" for z in range(2)]     # m2 = -inf
-    if prof:                         # s71..s75: cycles in M, at the barrier behind it, in V, in the DMA wait, at the barrier behind that
-        out += ["s_memtime s[68:69]", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s70, s68"] + [f"s_mov_b32 s{a}, 0" for a in range(71, 76)]
-    if ALIGN:
-        out += [".p2align 8"] + (["s_nop 0"] if ALIGN.endswith("+4") else [])
-    out += ["L_loop_%=:"]
+def group_loop(g, masked, prof):
+    """the phase loop of key group g (tiles t = g, g + 2, ...).  SYNC == "two": a barrier behind every phase (both groups alike; group 1
+    starts one phase late).  SYNC == "one": ONE barrier per iteration -- group 0 behind its vector phase, group 1 behind its matrix
+    phase -- so that a wave runs M(t), V(t) back to back and an iteration costs M + V instead of 2 max(M, V) + a second barrier; the
+    groups still sit in opposite phases (group 0: M, V | barrier; group 1: M | barrier | V, its first interval holding M(1) only)."""
+    L = lambda name: f"L_{name}{g}_%="
+    out = [L("loop") + ":"]
     # qk = t < n_live;  pv = t >= 2 && t - 2 < n_live
     out += [f"s_cmp_lt_i32 {sr(ST)}, {sr(SNLIVE)}", f"s_cselect_b32 {sr(SQK)}, 1, 0",
             f"s_sub_i32 {sr(SA)}, {sr(ST)}, 2", f"s_cmp_lt_i32 {sr(SA)}, {sr(SNLIVE)}", f"s_cselect_b32 {sr(SPV)}, 1, 0",
@@ -326,33 +323,61 @@ def loop(masked, prof=False):
     out += [f"v_add_u32 {vr(KIMG)}, {sr(SKA)}, {vr(KLANE)}", f"v_add_u32 {vr(VIMG)}, {sr(SVA)}, {vr(VLANE)}",
             f"s_add_i32 {sr(SA)}, {sr(ST)}, 4", f"s_lshl_b32 {sr(SA)}, {sr(SA)}, {TILE_SHIFT}", f"s_min_u32 {sr(SKOFF)}, {sr(SA)}, {sr(SLAST)}",
             f"s_add_i32 {sr(SA)}, {sr(ST)}, 2", f"s_lshl_b32 {sr(SA)}, {sr(SA)}, {TILE_SHIFT}", f"s_min_u32 {sr(SVOFF)}, {sr(SA)}, {sr(SLAST)}"]
-    out += [f"s_cmp_eq_u32 {sr(SQK)}, 0", "s_cbranch_scc1 L_noqk_%=", f"s_cmp_eq_u32 {sr(SPV)}, 0", "s_cbranch_scc1 L_mqk_%="]
-    out += m_phase(True, True, masked) + ["s_branch L_mdone_%=", "L_mqk_%=:"] + m_phase(True, False, masked) + ["s_branch L_mdone_%=", "L_noqk_%=:"]
-    out += [f"s_cmp_eq_u32 {sr(SPV)}, 0", "s_cbranch_scc1 L_mnone_%="] + m_phase(False, True, masked) + ["s_branch L_mdone_%=", "L_mnone_%=:"]
-    out += m_phase(False, False, masked) + ["L_mdone_%=:"] + (tick(71) if prof else []) + ["s_barrier"] + (tick(72) if prof else [])
-    out += [f"s_add_i32 {sr(SA)}, {sr(ST)}, 1", f"s_cmp_ge_i32 {sr(SA)}, {sr(SH)}", "s_cbranch_scc1 L_exit_%=",
-            f"s_cmp_eq_u32 {sr(SQK)}, 0", "s_cbranch_scc1 L_vnone_%="]
-    # ---- vector phase.  It opens with two pieces of the DMA batch: behind them the last QK^T MFMAs of the matrix phase (issued right in
-    # front of the barrier; the final pass of an MFMA issued behind a busy pipe lands up to 64 cycles after its issue) have landed
+    out += [f"s_cmp_eq_u32 {sr(SQK)}, 0", f"s_cbranch_scc1 {L('noqk')}", f"s_cmp_eq_u32 {sr(SPV)}, 0", f"s_cbranch_scc1 {L('mqk')}"]
+    out += m_phase(True, True, masked) + [f"s_branch {L('mdone')}", L("mqk") + ":"] + m_phase(True, False, masked) + [f"s_branch {L('mdone')}", L("noqk") + ":"]
+    out += [f"s_cmp_eq_u32 {sr(SPV)}, 0", f"s_cbranch_scc1 {L('mnone')}"] + m_phase(False, True, masked) + [f"s_branch {L('mdone')}", L("mnone") + ":"]
+    out += m_phase(False, False, masked) + [L("mdone") + ":"] + (tick(71) if prof else [])
+    # the DMA batch issued one iteration ago -- K(t+2), V(t): what M(t+2) reads -- has landed; behind the barrier every wave's has
+    sync = (tick(73) if prof else []) + [f"s_waitcnt vmcnt({NJK + NJV})"] + (tick(74) if prof else []) + ["s_barrier"] + (tick(75) if prof else [])
+    if SYNC == "two":
+        out += ["s_barrier"] + (tick(72) if prof else [])
+        out += [f"s_add_i32 {sr(SA)}, {sr(ST)}, 1", f"s_cmp_ge_i32 {sr(SA)}, {sr(SH)}", f"s_cbranch_scc1 {L('exit')}"]
+    elif g == 1:
+        out += sync
+    out += [f"s_cmp_eq_u32 {sr(SQK)}, 0", f"s_cbranch_scc1 {L('vdone')}"]
+    # ---- vector phase
     out += ["@VP1@"] + (dma_piece(0) + dma_piece(1) + ["s_nop 15", "s_nop 15"] if DMA_AT == "v" else [])
     if masked:
-        out += ["s_waitcnt lgkmcnt(0)"] + v_mask()
+        out += ["s_waitcnt lgkmcnt(0)"] + v_mask(g)
     out += ([f"s_mov_b64 {SM}, 0", "s_cmp_lg_u32 0, 0"] if ABL & 2 else v_rowmax())
-    out += ["s_cbranch_scc1 L_rescale_%=", "L_rescdone_%=:"]          # (s_or_b64 sets SCC = result != 0)
-    out += ([] if ABL & 4 else v_softmax(dma_at=(16, 40) if DMA_AT == "v" else ())) + ["@VP0@", "s_branch L_vdone_%=", "L_vnone_%=:"]
+    out += [f"s_cbranch_scc1 {L('rescale')}", L("rescdone") + ":"]          # (s_or_b64 sets SCC = result != 0)
+    out += ([] if ABL & 4 else v_softmax(dma_at=(16, 40) if DMA_AT == "v" else ())) + ["@VP0@"]
     if DMA_AT == "v":                # a wave without the tile keeps the group's DMA schedule
+        out += [f"s_branch {L('vdone2')}", L("vdone") + ":"]
         for d in range(NJK + NJV):
             out += dma_piece(d)
-    # the DMA batch issued one iteration ago -- K(t+2), V(t): what M(t+2) reads -- has landed; behind the barrier every wave's has
-    out += ["L_vdone_%=:"] + (tick(73) if prof else []) + [f"s_waitcnt vmcnt({NJK + NJV})"] + (tick(74) if prof else []) + ["s_barrier"] + (tick(75) if prof else [])
+        out += [L("vdone2") + ":"]
+    else:
+        out += [L("vdone") + ":"]
+    if SYNC == "two" or g == 0:
+        out += sync
     # t += 2: the group's slots of either ring rotate, (A, B[, C]) <- (B[, C], A)
     for x, y, z in ((SKA, SKB, SKC), (SVA, SVB, SVC)):
         if SLOTS == 2:
             out += [f"s_mov_b32 {sr(SA)}, {sr(x)}", f"s_mov_b32 {sr(x)}, {sr(y)}", f"s_mov_b32 {sr(y)}, {sr(SA)}"]
         else:
             out += [f"s_mov_b32 {sr(SA)}, {sr(x)}", f"s_mov_b32 {sr(x)}, {sr(y)}", f"s_mov_b32 {sr(y)}, {sr(z)}", f"s_mov_b32 {sr(z)}, {sr(SA)}"]
-    out += [f"s_add_i32 {sr(ST)}, {sr(ST)}, 2", f"s_cmp_lt_i32 {sr(ST)}, {sr(SH)}", "s_cbranch_scc1 L_loop_%=", "s_branch L_exit_%=",
-            "L_rescale_%=:"] + rescale() + ["s_branch L_rescdone_%=", "L_exit_%=:"]
+    out += [f"s_add_i32 {sr(ST)}, {sr(ST)}, 2", f"s_cmp_lt_i32 {sr(ST)}, {sr(SH)}", f"s_cbranch_scc1 {L('loop')}"]
+    if SYNC == "one" and g == 1:
+        # group 0 runs ceil(H / 2) iterations = barriers, group 1 floor(H / 2): one more when H is odd
+        out += [f"s_bitcmp1_b32 {sr(SH)}, 0", f"s_cbranch_scc0 {L('exit')}", "s_barrier"]
+    out += [f"s_branch {L('exit')}", L("rescale") + ":"] + rescale() + [f"s_branch {L('rescdone')}", L("exit") + ":"]
+    return out
+
+
+def loop(masked, prof=False):
+    """the statement: group 0's loop and group 1's loop (SYNC == "two": one loop for both, group 1 enters it behind a barrier of its
+    own in front of the statement).  Half-steps h = 0 .. n_tiles + 1: group g runs M(t) at h = t for t = g (mod 2) and V(t) at h = t + 1;
+    PV(t) happens in M(t + 2)."""
+    out = []
+    out += [f"v_mov_b32 {vr(NM(z))}, 0" for z in range(2)] + [f"v_mov_b32 {vr(THR(z))}, 0xff800000" for z in range(2)]     # m2 = -inf
+    if prof:                         # s71..s75: cycles in M, at the barrier behind it, in V, in the DMA wait, at the barrier behind that
+        out += ["s_memtime s[68:69]", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s70, s68"] + [f"s_mov_b32 s{a}, 0" for a in range(71, 76)]
+    if SYNC == "two":
+        out += group_loop(0, masked, prof)
+    else:
+        out += [f"s_cmp_lg_u32 {sr(ST)}, 0", "s_cbranch_scc1 L_loop1_%="]      # t = the wave's key group on entry
+        out += group_loop(0, masked, prof) + ["s_branch L_end_%="] + group_loop(1, masked, prof) + ["L_end_%=:"]
     if prof:
         out += [f"v_mov_b32 v{224 + i}, s{71 + i}" for i in range(5)]
     return out
@@ -364,9 +389,9 @@ def check_stream(lines):
          the n youngest requests), and no LDS read overwrites a fragment register that is still waiting to be consumed;
       2. a transcendental's result is not read by the very next instruction (one wait state, gfx940+);
       3. v_permlane32_swap is not directly behind a VALU write of its operands (two wait states); s_mov m0 -> LDS-DMA has its s_nop;
-      4. behind the barrier that closes a matrix phase, >= 16 vector instructions (>= 64 cycles) precede the first read of a score
-         register of key block 1 -- the last QK^T MFMAs were issued right in front of that barrier (key block 0 was finished 8 MFMAs
-         earlier) -- unless explicit idle cycles do the same;
+      4. behind the last QK^T MFMA of a matrix phase, >= 16 instructions (>= 64 cycles at 4 cycles of issue each) or as many explicit
+         idle cycles precede the first vector read of a score register of key block 1 (key block 0 was finished 8 MFMAs earlier): the
+         final pass of an MFMA issued behind a busy pipe lands up to 64 cycles after its issue;
       5. the P^T words an MFMA reads were all written (v_cvt_pk) in the vector phase before (structural: same registers as S)."""
     import re
     reg_re = re.compile(r"v\[(\d+):(\d+)\]|\bv(\d+)\b")
@@ -416,7 +441,7 @@ def check_stream(lines):
         if op.startswith("buffer_load") and prev.startswith("s_mov_b32 m0"):
             assert False, f"LDS-DMA directly behind the M0 write: {ln}"
         # rule 4
-        if op == "s_barrier":
+        if op.startswith("v_mfma_f32_32x32x16") and regs(args[0]) & (set(range(S(0, 1), S(0, 1) + 16)) | set(range(S(1, 1), S(1, 1) + 16))):
             since_barrier, idle = 0, 0
         elif since_barrier is not None and op:
             if op == "s_nop":
@@ -424,12 +449,14 @@ def check_stream(lines):
             elif op.startswith("v_") and not op.startswith("v_mfma"):
                 kb1 = set(range(S(0, 1), S(0, 1) + 16)) | set(range(S(1, 1), S(1, 1) + 16))
                 if set().union(*[regs(a) for a in args[1:]]) & kb1:
-                    assert 4 * since_barrier + idle >= 64, f"score registers of key block 1 read {since_barrier} instructions behind the barrier: {ln}"
+                    assert 4 * since_barrier + idle >= 64, f"score registers of key block 1 read {since_barrier} instructions behind the MFMA that writes them: {ln}"
                     since_barrier = None
                 else:
                     since_barrier += 1
             elif op.startswith("v_mfma"):
                 since_barrier = None
+            elif op.startswith("buffer_") or op.startswith("s_"):
+                since_barrier += 1
         if op:
             prev = ln
     return True
@@ -447,7 +474,8 @@ def render():
     parts = ["// GENERATED by tools/gen_duo_asm.py -- do not edit; tests/test_duo_codegen.py checks that it is up to date.\n"
              "// The phase loop of fa_fwd_duo.hpp with fixed physical registers (register map: the generator's header).\n"
              "// TS: the element type's mnemonic suffix (\"bf16\" / \"f16\").\n"
-             f"#define NNOP_DUO_SLOTS_PER_GROUP {SLOTS}      // ring slots per key group and ring (where the DMA batch is issued decides)\n"]
+             f"#define NNOP_DUO_SLOTS_PER_GROUP {SLOTS}      // ring slots per key group and ring (where the DMA batch is issued decides)\n"
+             f"#define NNOP_DUO_SYNC_ONE {1 if SYNC == 'one' else 0}             // 1: one barrier per iteration, no barrier of group 1 in front of the statement\n"]
     for masked in (False, True):
         check_stream(loop(masked))
     parts.append(as_macro("NNOP_DUO_LOOP_PLAIN", loop(False)))

@@ -1,6 +1,7 @@
 """dev: per-tile cost of the forward's modes on the SAME non-causal problem: plain split-KV, plain 8-wave (knob fwd_split=0),
 masked mode via an all-valid key-padding mask; and the causal run of the same shape.  usage: perf_modes.py [dt:E:L:H:B ...]"""
 import os, sys, torch
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge

@@ -3,6 +3,7 @@ direct: gather / scatter in the reference layout, chosen when the caller brings 
 pair-bias benchmark shape (benchmarks/main.jl:306-315: E 64, L 2048, H 4, B 4).  Run under tools/prof_pair_modes.sh for per-kernel times.
 usage: perf_pair_modes.py [dt] [L] [H] [B]"""
 import os, sys, torch
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 pkg = ge.load_package(); dev = torch.device("cuda:0")

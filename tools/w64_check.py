@@ -2,6 +2,7 @@
 max |diff| relative to max |o| for o / ms / ls, and the time of each.  usage: w64_check.py [dt:E:L:QH:KH:B:mode ...]
 mode: plain | causal | lens (variable-length key mask) | ragged (KL = L - 37)"""
 import os, sys, torch
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge

@@ -1,6 +1,7 @@
 """dev: forward time vs number of kv tiles at a constant 256 workgroups (one per CU): fixed cost per workgroup + cost per tile,
 for the 64-row form (knob fwd_w64=1) and the shipped default (-1).  usage: w64_scan.py [E ...]"""
 import os, sys, torch
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge

@@ -2,6 +2,7 @@
 NNOP_LIB_PATH): prologue / loop / epilogue duration per workgroup in shader cycles, cycles per kv tile, cycles per MFMA and the
 in-kernel clock (delta s_memtime / delta s_memrealtime x 100 MHz).  usage: w64_stamp.py dt:E:L:QH:KH:B[:causal] ..."""
 import os, sys, torch
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge

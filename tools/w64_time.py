@@ -2,6 +2,7 @@
 launches as warm-up (clock settles), then 3 timed batches.  usage: w64_time.py [--w64 N] dt:E:L:QH:KH:B:mode ...   (mode as in w64_check.py)
 A/B between libraries: run it once per NNOP_LIB_PATH (tools/w64_ab.sh alternates them on one box)."""
 import os, sys, torch
+os.environ.setdefault("NNOP_DEBUG_HOOKS", "1")          # unlock the kernel-form hook nnop_debug_set (csrc/nnop_debug.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
