@@ -36,8 +36,9 @@ def test_audit_flags_a_missing_wait_and_a_short_distance():
     i = next(k for k, ln in enumerate(lines) if ln.startswith("s_waitcnt lgkmcnt"))
     with pytest.raises(AssertionError, match="not waited for"):
         g.check_stream(lines[:i] + lines[i + 1:])
-    # a vector phase that opens with the key-block-1 logits: they may not have left the matrix pipe yet
-    j = next(k for k, ln in enumerate(lines) if ln == "s_barrier")
+    # a vector read of the key-block-1 logits right behind the MFMAs that write them: they may not have left the matrix pipe yet
+    kb1 = g.vr(g.S(1, 1), 16)
+    j = max(k for k, ln in enumerate(lines[:len(lines) // 2]) if ln.startswith("v_mfma_f32_32x32x16") and ln.split()[1].startswith(kb1))
     bad = lines[:j + 1] + [f"v_max_f32 v212, {g.vr(g.S(0, 1))}, {g.vr(g.S(0, 1) + 1)}"] + lines[j + 1:]
     with pytest.raises(AssertionError, match="key block 1"):
         g.check_stream(bad)
