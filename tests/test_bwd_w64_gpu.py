@@ -166,27 +166,34 @@ def test_e256(pkg, dev, tune, dt, QL, KL, QH, KH, causal, pad):
 
 
 @pytest.mark.parametrize("E", [64, 128])
-def test_misaligned_workspace_takes_the_fallback(pkg, dev, tune, E):
-    """The fragment form of the row constants is written with 16-byte stores and copied by LDS-DMA: with a workspace that is not
-    16-byte aligned the dK/dV pass falls back to the 32-row kernel (the dQ pass keeps the new form, with the separate preprocess).
-    Same results either way."""
+def test_misaligned_bases_are_refused_through_the_c_abi(pkg, dev, E):
+    """NNOP_ERR_ALIGN (include/nnop_hip.h, round 4): the kernels move tensors and the workspace with 16-byte vector accesses and LDS-DMA
+    from the raw base, so an offset pointer is refused by the boundary BEFORE anything is launched -- forward (q 8 bytes off) and backward
+    (workspace 8 bytes off; round 3 fell back to the 32-row dK/dV kernel instead) -- and the aligned call right behind it still works."""
     d = make_inputs(90, 2, 4, 2, 300, 300, E, "bf16", dev)
     o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], None, causal=True, kpad_mask=None)
+    # forward: a q that starts 8 bytes into its allocation
+    raw_q = torch.empty(d["q"].numel() + 8, dtype=d["q"].dtype, device=dev)
+    q_off = raw_q[4:4 + d["q"].numel()].view_as(d["q"])
+    q_off.copy_(d["q"])
+    assert q_off.data_ptr() % 16 == 8
+    o2, ms2, ls2 = torch.empty_like(o), torch.empty_like(ms), torch.empty_like(ls)
+    with pytest.raises(pkg.NNopError) as e:
+        pkg.fa_fwd_into(o2, ms2, ls2, q_off, d["k"], d["v"], causal=True)
+    assert e.value.status == pkg._lib.NNOP_ERR_ALIGN
+    # backward: the workspace 8 bytes off
     nbytes = pkg.bwd_workspace_bytes(d["q"], d["k"], d["v"], causal=True)
     raw = torch.empty(nbytes + 64, dtype=torch.uint8, device=dev)
-    outs = []
-    for off in (0, 8):
-        ws = raw[off:off + nbytes]
-        assert ws.data_ptr() % 16 == off
-        dq, dk, dv = torch.empty_like(d["q"]), torch.empty_like(d["k"]), torch.empty_like(d["v"])
-        pkg.fa_bwd_into(dq, dk, dv, None, ws, d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=True)
-        torch.cuda.synchronize()
-        outs.append((dq, dk, dv))
+    dq, dk, dv = torch.empty_like(d["q"]), torch.empty_like(d["k"]), torch.empty_like(d["v"])
+    with pytest.raises(pkg.NNopError) as e:
+        pkg.fa_bwd_into(dq, dk, dv, None, raw[8:8 + nbytes], d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=True)
+    assert e.value.status == pkg._lib.NNOP_ERR_ALIGN
+    pkg.fa_bwd_into(dq, dk, dv, None, raw[:nbytes], d["do"], o, ms, ls, d["q"], d["k"], d["v"], causal=True)
+    torch.cuda.synchronize()
     rq, rk, rv, _ = oracle_bwd(d, True)
-    for dq, dk, dv in outs:
-        assert_close("dq", dq, rq, "bf16", kind="grad")
-        assert_close("dk", dk, rk, "bf16", kind="grad")
-        assert_close("dv", dv, rv, "bf16", kind="grad")
+    assert_close("dq", dq, rq, "bf16", kind="grad")
+    assert_close("dk", dk, rk, "bf16", kind="grad")
+    assert_close("dv", dv, rv, "bf16", kind="grad")
 
 
 @pytest.mark.parametrize("dt,E,QH,KH,L,causal,pad,ragged", [

@@ -16,7 +16,9 @@ TORCH_DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 # comparisons, profiles/r03/parity_errors.json): worst error / tolerance bf16 0.65 (dq), f16 0.44, f32 0.75 (dk) -- unchanged tolerances.
 RTOL = {"f32": 1e-4, "f16": 4e-3, "bf16": 8e-3}
 ATOL_FRAC = {"f32": 1e-5, "f16": 8e-4, "bf16": 8e-3}
-GRAD_SCALE = {"f32": 1.0, "f16": 2.0, "bf16": 1.6}
+# gradients: the residuals ms, ls they are computed from are stored in T (src/attention.jl:128-129).  Round 4: the 16-bit gates are INSIDE
+# north_star's rtol <= 1e-2 (bf16: 8e-3 x 1.25 = 1.0e-2, fp16: 4e-3 x 2 = 8e-3; round 3 enforced 1.28e-2 for bf16 gradients)
+GRAD_SCALE = {"f32": 1.0, "f16": 2.0, "bf16": 1.25}
 
 
 def make_inputs(seed, B, QH, KH, QL, KL, E, dt, dev, *, pair=False, pad=None, need_do=True):
