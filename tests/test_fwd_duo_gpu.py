@@ -1,0 +1,172 @@
+"""GPU parity of the two-waves-per-SIMD forward (csrc/fa_fwd_duo.hpp; its phase loop is generated asm with fixed registers,
+tools/gen_duo_asm.py) -- forced on with the test hook, since the launcher itself picks it only from KL = 1024 up -- against the fp64
+oracle in every mode it serves: plain, causal, key padding (reference pattern, prefix lengths, random), ragged QL / KL, GQA, tile
+counts 1, 2, 3, 4 (the pipeline's start-up: a key group with no tile at all, the matrix-phase variants QK-only / PV-only / empty),
+odd and even; plus what a tolerance check can miss in a hand-written loop: bitwise reproducibility across launches (an LDS ring slot
+overwritten early, an LDS read consumed before its wait, a score register read before its MFMA has landed would all come and go
+with timing), the persistent block list against the one-block-per-workgroup launch, a forced rise of the deferred-max reference at
+chosen tiles of either key group (the rare branch: O and the row sums, which live in lanes 0..15 in the 16x16x32 layout, are
+rescaled), rows that see no key, and the merge of the two key groups when one of them saw nothing."""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_close, make_inputs, oracle_fwd
+
+pytestmark = pytest.mark.gpu
+
+
+def run(pkg, d, causal):
+    o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=causal, kpad_mask=d["mask"])
+    torch.cuda.synchronize()
+    return o, ms, ls
+
+
+def check(pkg, d, causal, dt):
+    o, ms, ls = run(pkg, d, causal)
+    o_ref, ms_ref, ls_ref = oracle_fwd(d, causal)
+    assert_close("o", o, o_ref, dt)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lse = ms.double().cpu().numpy() + np.log(ls.double().cpu().numpy())
+        lse_ref = ms_ref + np.log(ls_ref)
+    assert_close("lse", lse, lse_ref, dt)
+    assert_close("ms", ms, ms_ref, dt)
+    return o, ms, ls
+
+
+def test_the_launcher_picks_the_form_where_it_measured_faster(pkg):
+    mk = lambda **kw: pkg._lib.FaDesc(**dict(dict(dtype=2, emb=64, ql=4096, kl=4096, qh=4, kh=4, batch=4, causal=0, emb_k=0, emb_v=0, kl_v=0, kh_v=0), **kw))
+    f = pkg._lib.fwd_form
+    assert f(mk()) == "fa_fwd_duo_kernel"                                   # C2, the headline shape
+    assert f(mk(dtype=1, kl=1024, ql=1024)) == "fa_fwd_duo_kernel"          # plain mode from KL = 1024
+    assert f(mk(kl=512, ql=512)) != "fa_fwd_duo_kernel"                     # short key axes: prologue + merge dominate
+    assert f(mk(causal=1, kl=2048, ql=2048)) == "fa_fwd_duo_kernel"         # masked mode from KL = 2048 ...
+    assert f(mk(causal=1, kl=1024, ql=1024, qh=2, kh=2, batch=2)) != "fa_fwd_duo_kernel"     # ... or KL = 1024 with >= 128 workgroups
+    assert f(mk(emb=128)) == "fa_fwd_w64_kernel" and f(mk(dtype=0)) != "fa_fwd_duo_kernel"   # E = 64, 16-bit only
+    assert f(mk(), True, False) != "fa_fwd_duo_kernel"                      # no pair-bias mode
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("QL,KL", [(256, 64), (300, 128), (64, 192), (511, 256), (512, 1024), (1024, 320), (257, 704), (40, 2048)])
+def test_plain(pkg, dev, tune, dt, QL, KL):
+    tune(fwd_duo=1)
+    check(pkg, make_inputs(71, 2, 2, 2, QL, KL, 64, dt, dev, need_do=False), False, dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("L", [1, 63, 64, 65, 128, 255, 256, 257, 511, 777, 1024])
+@pytest.mark.parametrize("pad", [None, "ref"])
+def test_causal(pkg, dev, tune, dt, L, pad):
+    if pad == "ref" and L < 64:
+        pytest.skip("the reference pattern masks the last 11 keys")
+    tune(fwd_duo=1)
+    check(pkg, make_inputs(72, 2, 2, 2, L, L, 64, dt, dev, pad=pad, need_do=False), True, dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("pad", ["ref", "lens", "random"])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("QL,KL", [(700, 700), (300, 1000), (512, 448), (100, 37)])
+def test_key_padding_and_ragged(pkg, dev, tune, dt, pad, causal, QL, KL):
+    tune(fwd_duo=1)
+    check(pkg, make_inputs(73, 3, 2, 2, QL, KL, 64, dt, dev, pad=pad, need_do=False), causal, dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("QH,KH", [(4, 1), (6, 2), (8, 2)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_gqa(pkg, dev, tune, dt, QH, KH, causal):
+    tune(fwd_duo=1)
+    check(pkg, make_inputs(74, 2, QH, KH, 515, 515, 64, dt, dev, need_do=False), causal, dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_rows_and_batches_that_see_no_key(pkg, dev, tune, dt):
+    """a fully padded batch (every row: no visible key -> NaN rows, ms = -inf, as the naive formula gives) beside live ones, and
+    causal rows whose only keys are padded (left padding): the exponent reference stays -inf, P = 0, and the merge of the two key
+    groups must not turn (-inf) - (-inf) into a NaN for rows that DO have keys in the other group"""
+    tune(fwd_duo=1)
+    d = make_inputs(81, 3, 2, 2, 384, 384, 64, dt, dev, need_do=False)
+    m = np.ones((3, 384), dtype=bool)
+    m[1, :] = False                                           # batch 1: nothing visible
+    m[2, :100] = False                                        # batch 2: left padding -- causal rows 0..99 see nothing
+    m[0, 64:128] = False                                      # batch 0: the whole of tile 1 (key group 1's first tile) masked
+    d["mask"] = torch.tensor(m).to(dev)
+    for causal in (False, True):
+        o, ms, ls = run(pkg, d, causal)
+        o_ref, ms_ref, ls_ref = oracle_fwd(d, causal)
+        dead = ~np.isfinite(ms_ref)
+        assert dead.any() and (~dead).any()
+        assert np.array_equal(np.isnan(o.float().cpu().numpy()).all(-1), dead)
+        assert np.array_equal(~np.isfinite(ms.float().cpu().numpy()), dead)
+        live = ~dead
+        assert_close("o", o.float().cpu().numpy()[live], o_ref[live], dt)
+        assert_close("ms", ms.float().cpu().numpy()[live], ms_ref[live], dt)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("causal,pad", [(False, None), (True, "ref"), (False, "random")])
+def test_bitwise_reproducible_and_close_to_the_one_wave_form(pkg, dev, tune, dt, causal, pad):
+    d = make_inputs(75, 2, 4, 2, 1100, 1100, 64, dt, dev, pad=pad, need_do=False)
+    flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
+    tune(fwd_duo=1)
+    outs = []
+    for _ in range(5):
+        flush.fill_(1)
+        outs.append(run(pkg, d, causal))
+    for other in outs[1:]:
+        for a, b, name in zip(outs[0], other, ("o", "ms", "ls")):
+            assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), name
+    tune(fwd_duo=0, fwd_w64=1)
+    o0, ms0, ls0 = run(pkg, d, causal)
+    # both forms apply the exact fp32 scale: the row max is the same number; o differs by the summation order (two key groups)
+    assert torch.equal(torch.nan_to_num(outs[0][1].float()), torch.nan_to_num(ms0.float()))
+    scale = float(torch.nan_to_num(o0.float()).abs().max())
+    assert float(torch.nan_to_num(outs[0][0].float() - o0.float()).abs().max()) <= (1.0e-2 if dt == "bf16" else 2e-3) * scale
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("spike_tiles", [(1,), (2, 5), (0, 3, 4, 9), (10,)])
+def test_forced_rise_of_the_deferred_max(pkg, dev, tune, dt, spike_tiles):
+    """the rescale branch fires only when a row's max outgrows the exponent reference by 2^8 -- never on N(0,1) data after the
+    first tile.  Plant keys that are strongly aligned with some queries at chosen kv tiles (even tiles: key group 0, odd: group 1) so
+    that the running max jumps by far more than the threshold there, for a subset of the rows of a wave, and compare the FULL
+    output with the oracle (the exact fp32 scale holds the standard tolerance at any logit size)."""
+    rng = np.random.default_rng(76)
+    B, H, L, E = 1, 2, 704, 64
+    d = make_inputs(77, B, H, H, L, L, E, dt, dev, need_do=False)
+    q, k = d["q"].float().cpu().numpy(), d["k"].float().cpu().numpy()
+    for i, t in enumerate(spike_tiles):
+        rows = rng.choice(L, size=40, replace=False)
+        key = 64 * t + int(rng.integers(0, 64))
+        direction = rng.standard_normal(E).astype(np.float32)
+        direction /= np.linalg.norm(direction)
+        k[:, :, key] = direction * 6.0 * (i + 1) * np.sqrt(E)
+        q[:, :, rows] = q[:, :, rows] * 0.2 + direction * 6.0
+    tdt = d["q"].dtype
+    d["q"], d["k"] = torch.tensor(q).to(tdt).to(dev), torch.tensor(k).to(tdt).to(dev)
+    tune(fwd_duo=1)
+    check(pkg, d, False, dt)
+    check(pkg, d, True, dt)
+
+
+@pytest.mark.parametrize("dt,causal,pad,QL,KL", [
+    ("bf16", True, None, 2048, 2048), ("bf16", False, "random", 2048, 2048), ("f16", True, "lens", 2048 - 13, 2048 - 37),
+    ("f16", False, "lens", 2048, 1024 + 37)])
+def test_persistent_block_list_is_bitwise_the_one_block_per_workgroup_launch(pkg, dev, tune, dt, causal, pad, QL, KL):
+    """the persistent form (256 workgroups walking the static, balanced block list of fa_fwd_w64.hpp; knob fwd_persist) runs the same
+    per-block code: outputs and residuals bitwise equal, every block visited exactly once; repeated persistent launches bitwise
+    equal (the hand-over between two blocks is one barrier: rings, exchange buffer and validity words are rewritten behind it)"""
+    d = make_inputs(77, 4, 16, 4, QL, KL, 64, dt, dev, pad=pad, need_do=False)        # B x QH = 64 columns: 8 per XCD, 2 steps of 32 blocks
+    flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
+    tune(fwd_duo=1, fwd_persist=0)
+    ref = run(pkg, d, causal)
+    tune(fwd_duo=1, fwd_persist=1)
+    for _ in range(3):
+        flush.fill_(1)
+        got = run(pkg, d, causal)
+        for a, b, name in zip(ref, got, ("o", "ms", "ls")):
+            assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), name
+    o_ref, ms_ref, _ = oracle_fwd({k_: (v[:1] if isinstance(v, torch.Tensor) else v) for k_, v in d.items()}, causal)
+    assert_close("o", got[0][:1], o_ref, dt)
+    assert_close("ms", got[1][:1], ms_ref, dt)
