@@ -104,6 +104,31 @@ def _row_cases():
     return out
 
 
+def _cases_duo():
+    """third sweep: the two-waves-per-SIMD forward (csrc/fa_fwd_duo.hpp) forced on random 16-bit E = 64 shapes -- any length from 1,
+    ragged, GQA, every mask kind -- so that odd tile counts, key groups without a tile and waves without rows all occur"""
+    rng = np.random.default_rng(CASE_SEED + 11)
+    out = []
+    for i in range(24):
+        dt = str(rng.choice(["bf16", "f16"]))
+        KH = int(rng.choice([1, 2]))
+        QH = KH * int(rng.choice([1, 2, 4]))
+        B = int(rng.integers(1, 3))
+        QL = int(rng.integers(1, 1500))
+        KL = int(rng.integers(1, 1500)) if rng.random() < 0.5 else QL
+        causal = bool(rng.random() < 0.5)
+        pad = [None, None, "lens", "random"][int(rng.integers(0, 4))]
+        out.append((i, dt, 64, B, QH, KH, QL, KL, causal, pad))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases_duo(), ids=lambda c: "{}-{}-E{}-B{}-H{}x{}-L{}x{}-c{}-{}".format(*c[:9], c[9] or "nopad"))
+def test_random_case_on_the_two_wave_forward(pkg, dev, tune, case):
+    i, dt, E, B, QH, KH, QL, KL, causal, pad = case
+    tune(fwd_duo=1)
+    test_random_case(pkg, dev, (4000 + i, dt, E, B, QH, KH, QL, KL, causal, pad, False))
+
+
 @pytest.mark.parametrize("case", _row_cases(), ids=lambda c: "{}-{}-w{}-n{}-emb{}".format(*c))
 def test_random_row_ops(pkg, dev, case):
     """Softmax, RMSNorm, LayerNorm (forward + pullback) on random row counts / lengths: every register shape, the

@@ -89,11 +89,17 @@ def _run(pkg, dev, dt, c, causal):
 # problem without a pair bias is the one-wave-per-SIMD form (csrc/fa_bwd_w64.hpp) by default.  `form = "w64"` runs a grid point once
 # more with the 64-row forward FORCED (16-bit types, E = 64 -- and an E = 128 slice the reference does not have, in the causal and
 # GQA grids --, no pair bias: that mode stays on the 32-row kernel); the two 16-bit types alternate over the points (suite time).
-FORMS = ["auto", "w64"]
+# Round 4: `form = "duo"` does the same for the two-waves-per-SIMD forward (csrc/fa_fwd_duo.hpp: 16-bit, E = 64, no pair bias) -- the
+# kernel bench.py times at C2; the launcher picks it from KL = 1024 up only.  It takes the OTHER 16-bit type of each point.
+FORMS = ["auto", "w64", "duo"]
 
 
 def _w64_applies(dt, E, use_pair, salt):
     return dt != "f32" and E in (64, 128) and not use_pair and (dt == "f16") == (salt % 2 == 1)
+
+
+def _duo_applies(dt, E, use_pair, salt):
+    return dt != "f32" and E == 64 and not use_pair and (dt == "f16") == (salt % 2 == 0)
 
 
 # test/attention_tests.jl:6-20  (form, dt on top = vary fastest, so the oracle cache of a grid point serves all its runs)
@@ -109,11 +115,15 @@ def test_flash_attention_grid(pkg, dev, tune, dt, form, KL, QL, E, use_pair, use
         if not _w64_applies(dt, E, use_pair, QL + KL + use_padmask) or E != 64:
             pytest.skip("64-row forward: 16-bit, E = 64, no pair bias")
         tune(fwd_w64=1, bwd_w64=1)
-    if dt == "f16" and (E < 64 or use_pair) and form == "auto":
+    if form == "duo":
+        if not _duo_applies(dt, E, use_pair, QL + KL + use_padmask):
+            pytest.skip("two-waves-per-SIMD forward: 16-bit, E = 64, no pair bias; the two types alternate")
+        tune(fwd_duo=1, bwd_w64=1)
+    if dt == "f16" and (E < 64 or (use_pair and QL != KL)) and form == "auto":
         # suite time (round-2 verdict: drop dtype repeats where the kernel form is identical): fp16 and bf16 run the same kernel
-        # templates and differ in the MFMA opcode only; fp16 stays on the E = 64 slice without a bias here and on every E in the
-        # causal / GQA grids
-        pytest.skip("fp16 at E < 64 or with a pair bias: same kernel form as bf16")
+        # templates and differ in the MFMA opcode only; fp16 stays on the E = 64 slice without a bias here, on the QL = KL slice
+        # WITH a pair bias (round-3 verdict: fp16 x pair was not in this grid at all), and on every E in the causal / GQA grids
+        pytest.skip("fp16 at E < 64, or with a pair bias off the QL = KL slice: same kernel form as bf16")
     H, B = 2, 3
     c = _case(("att", use_padmask, use_pair, E, QL, KL), B, H, H, QL, KL, E, False, use_padmask, use_pair)
     _run(pkg, dev, dt, c, False)
@@ -131,6 +141,10 @@ def test_causal_flash_attention_grid(pkg, dev, tune, dt, form, L, E, use_pair, u
         if dt == "f32" or E not in (64, 128) or use_pair:
             pytest.skip("64-row forward: 16-bit, E = 64 / 128, no pair bias")
         tune(fwd_w64=1, bwd_w64=1)
+    elif form == "duo":
+        if dt == "f32" or E != 64 or use_pair:
+            pytest.skip("two-waves-per-SIMD forward: 16-bit, E = 64, no pair bias")
+        tune(fwd_duo=1, bwd_w64=1)
     elif E == 128:
         pytest.skip("E = 128 is not in the reference's grid: the added slice runs on the 64-row kernels only")
     H, B = 2, 3
@@ -151,6 +165,10 @@ def test_grouped_query_attention_grid(pkg, dev, tune, dt, form, L, E, causal, KV
         if not _w64_applies(dt, E, False, L + QH + KVH + causal) or L == 256:
             pytest.skip("64-row forward: 16-bit, E = 64 / 128; the two types alternate")
         tune(fwd_w64=1, bwd_w64=1)
+    elif form == "duo":
+        if not _duo_applies(dt, E, False, L + QH + KVH + causal):
+            pytest.skip("two-waves-per-SIMD forward: 16-bit, E = 64; the two types alternate")
+        tune(fwd_duo=1, bwd_w64=1)
     elif E == 128:
         pytest.skip("E = 128 is not in the reference's grid: the added slice runs on the 64-row kernels only")
     B = 2
