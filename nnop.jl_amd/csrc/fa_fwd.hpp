@@ -89,6 +89,7 @@ struct FwdParams {
     float scale;             // 1/sqrt(E)
     int   persist_hx = 0;    // persistent form: heads per XCD when QH % 8 == 0 (the XCD's columns = those heads of every batch), else 0
     int   persist = 0;       // fa_fwd_w64_kernel: blocks per workgroup of the persistent form (grid = 256 workgroups), 0 = one block per workgroup
+    int   persist_asc = 0;   // persistent form: q-blocks of a column in ASCENDING order (light blocks first), see fwd_persist_plan
 #ifdef NNOP_DEV_BUILD
     int   stagger = 0;       // experiment: s_sleep units for the odd co-resident workgroup (0 = off)
 #endif

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         const int x = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3;
         const int pos = 32 * pstep + ((pstep & 1) ? 31 - c : c);
         const int col = pos / p.n_qblk;
-        qblk = p.n_qblk - 1 - (pos - col * p.n_qblk);
+        qblk = p.persist_asc ? pos - col * p.n_qblk : p.n_qblk - 1 - (pos - col * p.n_qblk);
         if (p.persist_hx > 0) bh = (col / p.persist_hx) * p.QH + x * p.persist_hx + col % p.persist_hx;
         else bh = x * ((p.B * p.QH) >> 3) + col;
     } else {

@@ -105,6 +105,14 @@ static inline void fwd_persist_plan(const nnop_fa_desc& d, const FwdArgs& a, Fwd
         per_xcd % 32 == 0 && per_xcd / 32 >= 2 && per_xcd / 32 <= (1 << 24)) {
         p.persist = (int)(per_xcd / 32);
         p.persist_hx = hx;
+        // Order of a column's q-blocks: descending (heaviest first).  The ascending order (light blocks first, so that every
+        // workgroup starts at kv tile 0 together and the heavy blocks follow staggered inside each other's L2 window) was built and
+        // measured in round 4: same time (+-0.1 %: C3 3912 vs 3918 us, C5 shard 15084 vs 15100 us), MORE fabric traffic at the C5
+        // shard (7.93 vs 6.11 GB per launch; C3 2.34 vs 2.32 GB) -- profiles/r04/persist_order.log.  Knob kTuneFwdPersistAsc (1 = ascending).
+        {
+            const int asc = tune_get(kTuneFwdPersistAsc);
+            p.persist_asc = asc >= 0 ? (asc != 0) : 0;
+        }
         grid = 256;
     }
 }

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p_ar
         p_blk.pair = nullptr;
         p_blk.o = pp->o; p_blk.ms = pp->ms; p_blk.ls = pp->ls; p_blk.q = pp->q; p_blk.k = pp->k; p_blk.v = pp->v; p_blk.kpad = pp->kpad;
         p_blk.QL = pp->QL; p_blk.KL = pp->KL; p_blk.QH = pp->QH; p_blk.KH = pp->KH; p_blk.B = pp->B; p_blk.causal = pp->causal;
-        p_blk.n_qblk = pp->n_qblk; p_blk.n_wg = pp->n_wg; p_blk.scale = pp->scale; p_blk.persist = pp->persist; p_blk.persist_hx = pp->persist_hx;
+        p_blk.n_qblk = pp->n_qblk; p_blk.n_wg = pp->n_wg; p_blk.scale = pp->scale; p_blk.persist = pp->persist; p_blk.persist_hx = pp->persist_hx; p_blk.persist_asc = pp->persist_asc;
     }
     const FwdParams& p = p_blk;
     const int vsplit = EV == E ? 0 : (int)blockIdx.x / p.n_wg;     // which column half (E = 256)
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_w64_kernel(const FwdParams p_ar
         const int x = (int)blockIdx.x & 7, c = (int)blockIdx.x >> 3;
         const int pos = 32 * pstep + ((pstep & 1) ? 31 - c : c);
         const int col = pos / p.n_qblk;
-        qblk = p.n_qblk - 1 - (pos - col * p.n_qblk);
+        qblk = p.persist_asc ? pos - col * p.n_qblk : p.n_qblk - 1 - (pos - col * p.n_qblk);
         // the XCD's columns: an eighth of the HEADS of every batch (batch-major) when the heads divide -- with per-batch key lengths
         // every XCD, and every step of 32 blocks, then sees every batch alike -- else a contiguous eighth of the (batch, head) pairs
         if (p.persist_hx > 0) bh = (col / p.persist_hx) * p.QH + x * p.persist_hx + col % p.persist_hx;

@@ -25,6 +25,7 @@ enum TuneKey {
     kTuneFwdPersist,     // NNOP_FWD_PERSIST 64-row forward as 256 persistent workgroups that walk a static block list: 0 never, 1 / auto wherever the list balances
     kTuneBwdPersist,     // NNOP_BWD_PERSIST the same for the one-wave-per-SIMD backward kernels
     kTuneFwdDuo,         // NNOP_FWD_DUO     two-waves-per-SIMD alternating-phase forward (fa_fwd_duo.hpp, 16-bit E = 64): 0 never, 1 wherever instantiated
+    kTuneFwdPersistAsc,  // NNOP_FWD_PERSIST_ASC persistent forward: q-blocks of a column ascending (light first: 1) / descending (0)
     kTuneCount
 };
 
