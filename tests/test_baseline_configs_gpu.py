@@ -22,6 +22,9 @@ C4_LENS = [3637, 2981, 2594, 1853, 1969, 1149, 1255, 1074, 1562, 3523, 3019, 382
 
 # name: dtype, E, L, QH, KH, B, causal, key lengths, (batch, kv-head) slices to check
 CONFIGS = {
+    # C1 is the reference's CPU-runnable case (bench.py's cpu_baseline leg); its fp32 GPU twin (bench.py --config c1gpu, the README's
+    # example shape) runs the 32-row fp32 kernels
+    "C1-gpu": ("f32", 64, 4096, 4, 4, 4, False, None, [(0, 1), (3, 3)]),
     "C2": ("bf16", 64, 4096, 4, 4, 4, False, None, [(0, 0), (3, 2)]),
     "C3": ("bf16", 128, 8192, 32, 32, 8, True, None, [(0, 0), (7, 31)]),
     "C4": ("f16", 128, 4096, 32, 8, 16, False, C4_LENS, [(7, 0), (14, 7)]),       # shortest and longest sequence
