@@ -9,7 +9,7 @@ import __graft_entry__ as ge
 pkg = ge.load_package()
 dev = torch.device("cuda:0")
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}
-pkg._lib.debug_set("fwd_w64", 1)
+pkg._lib.debug_set("fwd_w64", 1); pkg._lib.debug_set("fwd_duo", 0)      # (the two-waves-per-SIMD form has its own tool: duo_stamp.py)
 pkg._lib.debug_set("fwd_persist", 0)          # the stamps describe ONE block per workgroup (the persistent form would overwrite them per block)
 for c in sys.argv[1:] or ["bf16:64:4096:4:4:4"]:
     f = c.split(":"); dt, (E, L, QH, KH, B) = f[0], map(int, f[1:6]); causal = len(f) > 6 and f[6] == "causal"
