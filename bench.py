@@ -16,7 +16,7 @@ independent); the optional all-gather of O is timed sepa
                      rectangles per rank, pointer offsets only; a step = the rank's rectangles, one launch each.
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel (fa_fwd_w64_kernel at C2): algorithmic FLOPs per launch / average launch
+  roofline     -- dominant kernel (fa_fwd_duo_kernel at C2 since round 4; fa_fwd_w64_kernel at C3-C5): algorithmic FLOPs per launch / average launch
                   duration measured here with HIP events on the launch stream, against the dense
                   bf16 MFMA peak (2516.6 TFLOP/s = 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz).
   cpu_baseline -- the oracle's fp32 port of the reference's naive attention
