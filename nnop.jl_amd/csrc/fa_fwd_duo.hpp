@@ -13,20 +13,24 @@
 //     ones, each with its own online-softmax state (reference, sum, O); the two partial results are merged once, through LDS, in
 //     the epilogue (each partner finishes and stores 32 of the 64 rows).  64 rows per wave keep what the one-wave form has: every K /
 //     V fragment read from LDS feeds two MFMAs (z = 0, 1).
-//   * a wave alternates a MATRIX phase M(t) -- row sums of P(t-2) (ones x P^T, 8 MFMAs), S(t) = K(t) Q^T (16), O += V(t-2)^T P(t-2)^T
-//     (16), with the LDS fragment reads and its share of the LDS-DMA of K(t+2) and V(t) in the gaps -- and a VECTOR phase V(t): mask,
-//     row max, (rare) rescale, P = exp2(s c - m), convert.  One s_barrier closes every phase; group 1 runs one phase behind group 0,
-//     so at any time each SIMD holds one wave in its matrix phase and one in its vector phase.  Nothing is software-pipelined INSIDE
-//     a wave (one score tile, 256 registers per wave); the hardware overlaps the partners.
+//   * a wave alternates a MATRIX phase M(t) -- row sums of P(t-2) (8 MFMAs 16x16x32 with a selector operand, see below), O +=
+//     V(t-2)^T P(t-2)^T (16 MFMAs), S(t) = K(t) Q^T (16), fragment reads three ahead, and at its END the LDS-DMA batch K(t+4), V(t+2) --
+//     and a VECTOR phase V(t): [rare: mask] row max, test, [rare: raise the reference] P = exp2(s c - m), packed in place.  The matrix
+//     phase holds NOTHING but MFMAs and fragment reads: a VALU or LDS-DMA instruction between them stalls the in-order wave while its
+//     partner's vector phase holds the port, and the pipe idles (measured both ways: DESIGN.md section 4.1d, profiles/r04/
+//     duo_ablations.log).  Group 1 runs a phase behind group 0, so each SIMD always holds one wave in M and one in V; ONE s_barrier per
+//     iteration (group 0 behind V, group 1 behind M).  Nothing is software-pipelined INSIDE a wave; the hardware overlaps the partners.
 //   * registers (256 per wave, all arch VGPRs): O^T (64), Q fragments (32), row-sum accumulators (8), one score tile (64) whose
-//     registers also take the packed P^T words, a fragment ring (16).  That leaves hipcc's allocator no slack (given virtual
-//     16-register tuples it moved whole tiles between phases and spilled the Q fragments: 228-312 bytes of scratch per lane in every
-//     variant tried), so every tile has a HOME register and the phases are instruction streams generated with those registers
-//     (tools/gen_duo_asm.py -> fa_fwd_duo_asm.inc); C++ hands the tiles to each statement with the matching physical-register
-//     constraint and allocates only the remaining ~64 registers.  hipcc pads nothing around asm: the streams carry their own
-//     s_waitcnt lgkmcnt and wait states (same hazards as fa_fwd_w64.hpp).
-//   * K / V rings of 3 tiles each, filled by LDS-DMA (the group that reads a tile also copies it): K(t+2) and V(t) are issued in
-//     M(t), waited for at the end of V(t) (a whole phase later), published by the barrier behind it and read in M(t+2).
+//     registers also take the packed P^T words, a fragment ring (16), state and temporaries (32); 32 are hipcc's across the loop.
+//     hipcc could not be made to allocate this (given virtual 16-register tuples it moved whole tiles between phases and spilled the
+//     Q fragments: 228-660 bytes of scratch per lane in every C++ form tried; naming the accumulator file halves the arch budget), so
+//     every tile has a HOME register and the whole loop is ONE asm statement per mode, generated with those registers
+//     (tools/gen_duo_asm.py -> fa_fwd_duo_asm.inc, register map and loop structure in the generator's header); hipcc copies each tile
+//     in once.  It pads nothing inside asm: the stream carries its own s_waitcnt and wait states, audited by the generator
+//     (check_stream) and tests/test_duo_codegen.py.
+//   * K / V rings of 6 slots per tensor, 3 per key group (read now / landed or landing / free), filled by LDS-DMA (the group that
+//     reads a tile also copies it): the batch K(t+4), V(t+2) issued at the tail of M(t) goes to the group's free slots (what they
+//     held was read two barriers back), is waited for one iteration later (vmcnt(4)) and read in M(t+4) / M(t+4).
 //
 // Modes: 0 plain / 1 masked (causal, key padding, ragged KL).  Exact fp32 scale only.  Same numerics contract as the other forms
 // (fp32 softmax, deferred row max with threshold 2^8, O normalised once, residuals ms / ls per src/attention.jl:128-129); the
@@ -78,7 +82,6 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     using frag_t = typename Elem<T>::frag;
     using KImg   = RowImg<T, E>;
     using VImg   = ColImg<T, E>;
-    using MM     = MfmaAsm<T>;
     constexpr bool kGeneral = MODE != 0;
     constexpr int BK = 64, KB = 2, KS = E / 16, EB = E / 32, NS = 2 * NNOP_DUO_SLOTS_PER_GROUP;
     constexpr int KBYTES = KImg::bytes(BK), VBYTES = VImg::bytes(BK);
