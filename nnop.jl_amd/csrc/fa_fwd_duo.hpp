@@ -53,6 +53,11 @@
 namespace nnop {
 
 // Operands of the generated loop statement: every tile in its home register (register map: tools/gen_duo_asm.py)
+#if NNOP_DUO_VALU_SUMS
+#define NNOP_DUO_SUMS_OPERAND , "+{v[248:251]}"(lsum)
+#else
+#define NNOP_DUO_SUMS_OPERAND
+#endif
 #if NNOP_DUO_STAMP
 #define NNOP_DUO_PROF_OPERAND , "+{v[224:231]}"(profv)
 #else
@@ -62,7 +67,7 @@ namespace nnop {
     "+{v[0:15]}"(oacc[0][0]), "+{v[16:31]}"(oacc[0][1]), "+{v[32:47]}"(oacc[1][0]), "+{v[48:63]}"(oacc[1][1]), "+{v[64:79]}"(qf[0]),   \
         "+{v[80:95]}"(qf[1]), "+{v[96:99]}"(lacc[0]), "+{v[100:103]}"(lacc[1]), "+{v[104:107]}"(sel), "+{v[112:127]}"(sc[0][0]),      \
         "+{v[128:143]}"(sc[0][1]), "+{v[144:159]}"(sc[1][0]), "+{v[160:175]}"(sc[1][1]), "+{v[192:195]}"(mstate), [st] "+s"(s_t),      \
-        [ska] "+s"(s_ka), [skb] "+s"(s_kb), [skc] "+s"(s_kc), [sva] "+s"(s_va), [svb] "+s"(s_vb), [svc] "+s"(s_vc) NNOP_DUO_PROF_OPERAND \
+        [ska] "+s"(s_ka), [skb] "+s"(s_kb), [skc] "+s"(s_kc), [sva] "+s"(s_va), [svb] "+s"(s_vb), [svc] "+s"(s_vc) NNOP_DUO_PROF_OPERAND NNOP_DUO_SUMS_OPERAND \
         : "{v[196:203]}"(vconst), [sh] "s"(s_h), [snlive] "s"(s_nlive), [slast] "s"(s_last), [sc2] "s"(c2), [scq0] "s"(s_cq0),            \
           [svbits] "s"(s_vbits), [krs] "s"(krs), [vrs] "s"(vrs)                                                                       \
         : "memory", "vcc", "scc", "v108", "v109", "v110", "v111", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", \
@@ -295,6 +300,9 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
 #if NNOP_DUO_STAMP
     f32x8 profv = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #endif
+#if NNOP_DUO_VALU_SUMS
+    f32x4 lsum = {0.f, 0.f, 0.f, 0.f};                        // row sums, VALU form: two chains per query block, this lane's half of the keys
+#endif
 #if NNOP_DUO_PRIO == 2
     if (grp) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -337,10 +345,16 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     // key group's partial result for the rows it keeps)
     char* const mine = smem + wave * (8192 + 3 * 256);
     const char* const theirs = smem + (wave ^ 4) * (8192 + 3 * 256);
+#if NNOP_DUO_VALU_SUMS
+    lacc[0][0] = half_swap_sum(lsum[0] + lsum[1]);            // (both lane halves: lane l ^ 32 holds the same query's other keys)
+    lacc[1][0] = half_swap_sum(lsum[2] + lsum[3]);
+    auto row_sum = [&](const f32x4& l) -> float { return l[0]; };
+#else
     auto row_sum = [&](const f32x4& l) -> float {            // this lane's query r: lane r % 16, register r / 16
         const float l0 = __shfl(l[0], r & 15), l1 = __shfl(l[1], r & 15);
         return (r & 16) ? l1 : l0;
     };
+#endif
     auto give = [&](auto givec) {
         constexpr int ZG = decltype(givec)::value;
 #pragma unroll

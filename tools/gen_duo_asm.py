@@ -85,6 +85,10 @@ TILE_SHIFT = 13                      # one 64-key tile of E = 64 16-bit elements
 DMA_AT = os.environ.get("NNOP_DUO_GEN_DMA", "mtail")
 SLOTS = 2 if DMA_AT == "v" else 3
 
+# row sums of P: "mfma" = 8 v_mfma_f32_16x16x32 per tile in the matrix phase (selector operand), "valu" = 64 v_add_f32 per tile in the
+# vector phase (4 chains in v[248:251]).  Measured (profiles/r04/duo_sums.log): see DESIGN.md section 4.1d.
+SUMS = os.environ.get("NNOP_DUO_GEN_SUMS", "mfma")
+LS = lambda z, c: 248 + 2 * z + c
 SYNC = os.environ.get("NNOP_DUO_GEN_SYNC", "one")        # barriers per iteration: "two" (behind every phase) / "one" (group_loop)
 RING = int(os.environ.get("NNOP_DUO_GEN_RING", "4"))      # fragment ring slots (4 registers each): v[176:191] (+ v[224:...] beyond 4)
 PF = int(os.environ.get("NNOP_DUO_GEN_PF", "3"))          # fragments read ahead (< RING)
@@ -209,7 +213,7 @@ def m_phase(qk, pv, masked):
             out.append(f"v_xor_b32 {vr(KA(ks))}, {ks << 5}, {vr(KIMG)}")
     for p in range(PF):
         reads(p)
-    if pv:
+    if pv and SUMS == "mfma":
         for kk in range(2 * KB):
             for z in range(2):
                 out.append(f"v_mfma_f32_16x16x32_@T@ {vr(L(z), 4)}, {vr(SEL, 4)}, {vr(PW(kk, z), 4)}, {vr(L(z), 4)}")
@@ -266,6 +270,10 @@ def v_softmax(l1=4, l2=4, dma_at=()):
         if 0 <= e < 64:
             r, _, _, _ = reg(e)
             out.append(f"v_exp_f32 {vr(r)}, {vr(r)}")
+        a = step - l1 - 2
+        if SUMS == "valu" and 0 <= a < 64:
+            r, z, _, j = reg(a)
+            out.append(f"v_add_f32 {vr(LS(z, j & 1))}, {vr(LS(z, j & 1))}, {vr(r)}")
         m = step - l1 - l2
         if 0 <= m < 64 and (m & 1):
             r, z, kk, j = reg(m)
@@ -297,6 +305,9 @@ def rescale():
         for eb in range(EB):
             for i in range(16):
                 out.append(f"v_mul_f32 {vr(O(z, eb) + i)}, {vr(O(z, eb) + i)}, {vr(al)}")
+        if SUMS == "valu":
+            out += [f"v_mul_f32 {vr(LS(z, c))}, {vr(LS(z, c))}, {vr(al)}" for c in range(2)]
+            continue
         # the sums of queries n and n + 16 sit in registers 0 / 1 of lanes 0..15: fetch their factors from those queries' lanes
         out += [f"ds_bpermute_b32 {vr(b0)}, {vr(a0)}, {vr(al)}", f"ds_bpermute_b32 {vr(b1)}, {vr(a1)}, {vr(al)}", "s_waitcnt lgkmcnt(0)",
                 f"v_mul_f32 {vr(L(z))}, {vr(L(z))}, {vr(b0)}", f"v_mul_f32 {vr(L(z) + 1)}, {vr(L(z) + 1)}, {vr(b1)}"]
@@ -475,6 +486,7 @@ def render():
              "// The phase loop of fa_fwd_duo.hpp with fixed physical registers (register map: the generator's header).\n"
              "// TS: the element type's mnemonic suffix (\"bf16\" / \"f16\").\n"
              f"#define NNOP_DUO_SLOTS_PER_GROUP {SLOTS}      // ring slots per key group and ring (where the DMA batch is issued decides)\n"
+             f"#define NNOP_DUO_VALU_SUMS {1 if SUMS == 'valu' else 0}            // 1: row sums by v_add_f32 in the vector phase (4 chains in v[248:251])\n"
              f"#define NNOP_DUO_SYNC_ONE {1 if SYNC == 'one' else 0}             // 1: one barrier per iteration, no barrier of group 1 in front of the statement\n"]
     for masked in (False, True):
         check_stream(loop(masked))
