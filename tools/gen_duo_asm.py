@@ -83,7 +83,7 @@ TILE_SHIFT = 13                      # one 64-key tile of E = 64 16-bit elements
 # vector phase V(t), into the slots M(t) has just read (2 slots per group and ring).  Measured (profiles/r04/duo_ablations.log): the
 # vector phase is the longer one, and an LDS-DMA instruction stalls the issuing wave ~60 cycles WITHOUT using the vector port.
 DMA_AT = os.environ.get("NNOP_DUO_GEN_DMA", "mtail")
-SLOTS = 2 if DMA_AT == "v" else 3
+SLOTS = 2 if DMA_AT == "v" else 3                        # ("mmid" / "mmidq": between the MFMA pairs of the matrix phase)
 
 # row sums of P: "mfma" = 8 v_mfma_f32_16x16x32 per tile in the matrix phase (selector operand), "valu" = 64 v_add_f32 per tile in the
 # vector phase (4 chains in v[248:251]).  Measured (profiles/r04/duo_sums.log): see DESIGN.md section 4.1d.
@@ -217,6 +217,12 @@ def m_phase(qk, pv, masked):
         for kk in range(2 * KB):
             for z in range(2):
                 out.append(f"v_mfma_f32_16x16x32_@T@ {vr(L(z), 4)}, {vr(SEL, 4)}, {vr(PW(kk, z), 4)}, {vr(L(z), 4)}")
+    mid = {}
+    if DMA_AT.startswith("mmid") and len(stream) == NKF + NVF:
+        # one piece behind every fourth MFMA pair ("mmid") / behind the last four pairs but one ("mmidq"): the wave stalls ~60 cycles per
+        # piece with one MFMA in the pipe
+        at = (3, 7, 11, 15) if DMA_AT == "mmid" else (9, 11, 13, 15)
+        mid = {q: d for d, q in enumerate(at)}
     for p, (kind, idx) in enumerate(stream):
         reads(p + PF)
         out.append(f"s_waitcnt lgkmcnt({lds_issued - 1 - last_read[p]})")
@@ -230,12 +236,16 @@ def m_phase(qk, pv, masked):
             for z in range(2):
                 c = "0" if ks == 0 else vr(S(z, kb), 16)
                 out.append(f"v_mfma_f32_32x32x16_@T@ {vr(S(z, kb), 16)}, {vr(slot, 4)}, {vr(Q(z, ks), 4)}, {c}")
+        if p in mid:
+            out += dma_piece(mid[p])
     if qk and masked:
         # the validity word of tile t for the vector phase (issued last: nothing in this phase waits for it)
         out += [f"s_lshl_b32 {sr(SA)}, {sr(ST)}, 3", f"s_add_u32 {sr(SA)}, {sr(SA)}, {sr(SVBITS)}", f"v_mov_b32 {vr(T0)}, {sr(SA)}",
                 f"ds_read_b64 {vr(T0 + 2, 2)}, {vr(T0)}"]
-    if DMA_AT == "mtail":
+    if DMA_AT == "mtail" or (DMA_AT.startswith("mmid") and not mid):
         out += all_dma
+    elif DMA_AT.startswith("mmid"):
+        out += (["s_nop 15"] * 3 if qk else [])
     elif DMA_AT == "msplit":
         out += dma_piece(2) + dma_piece(3) + (["s_nop 15"] * 2 if qk else [])
     elif qk:
