@@ -75,15 +75,33 @@ namespace nnop {
           "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "s56", "s57", "s58", "s59", "s60", "s61",  \
           "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77"
 
+// NZ = 1: the z = 0 tiles only; v[144:175] (the z = 1 score tile's registers) are the loop's 8-slot fragment ring
+#define NNOP_DUO1_OPERANDS                                                                                                       \
+    "+{v[0:15]}"(oacc[0][0]), "+{v[16:31]}"(oacc[0][1]), "+{v[64:79]}"(qf[0]), "+{v[96:99]}"(lacc[0]), "+{v[104:107]}"(sel),              \
+        "+{v[112:127]}"(sc[0][0]), "+{v[128:143]}"(sc[0][1]), "+{v[192:195]}"(mstate), [st] "+s"(s_t), [ska] "+s"(s_ka), [skb] "+s"(s_kb), \
+        [skc] "+s"(s_kc), [sva] "+s"(s_va), [svb] "+s"(s_vb), [svc] "+s"(s_vc)                                                         \
+        : "{v[196:203]}"(vconst), [sh] "s"(s_h), [snlive] "s"(s_nlive), [slast] "s"(s_last), [sc2] "s"(c2), [scq0] "s"(s_cq0),            \
+          [svbits] "s"(s_vbits), [krs] "s"(krs), [vrs] "s"(vrs)                                                                       \
+        : "memory", "vcc", "scc", "v108", "v109", "v110", "v111", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", \
+          "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168",   \
+          "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v204",   \
+          "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220",   \
+          "v221", "v222", "v223", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70",    \
+          "s71", "s72", "s73", "s74", "s75", "s76", "s77"
+
 constexpr int kDuoXchgBytes = 8 * (8192 + 3 * 256);          // epilogue exchange: per wave 32 fp32 per lane + (l, m2, mt)
 template <typename T, int E> constexpr int fa_fwd_duo_lds_bytes(bool masked) {
     constexpr int ring = 2 * NNOP_DUO_SLOTS_PER_GROUP * (RowImg<T, E>::bytes(64) + ColImg<T, E>::bytes(64));
     return (ring > kDuoXchgBytes ? ring : kDuoXchgBytes) + (masked ? 16 + 8 * kMaxMaskTiles : 0);
 }
 
-template <typename T, int E, int MODE>
+// NZ: 32-row query blocks per wave.  2: 64 rows per wave, 256 per workgroup (the form described above).  1: the same loop with the z = 1
+// half left out -- 32 rows per wave, 128 per workgroup, for problems whose 256-row blocks cannot fill the chip (twice the workgroups;
+// every fragment then feeds one MFMA and the per-iteration overheads are paid per 32 rows: ~8 % more cycles per row).
+template <typename T, int E, int MODE, int NZ = 2>
 __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
-    static_assert(sizeof(T) == 2 && E == 64, "16-bit element types, E = 64");
+    static_assert(sizeof(T) == 2 && E == 64 && (NZ == 1 || NZ == 2), "16-bit element types, E = 64");
+    constexpr int RW = 32 * NZ, RB = 4 * RW;                  // query rows per wave / per workgroup
     using frag_t = typename Elem<T>::frag;
     using KImg   = RowImg<T, E>;
     using VImg   = ColImg<T, E>;
@@ -128,10 +146,10 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     }
     const int b = bh / p.QH, qh = bh - b * p.QH;
     const int kvh = qh / (p.QH / p.KH);                       // cld(q_head, n_q_per_kv), 0-based (src/attention.jl:28)
-    const int q0w = qblk * 256 + wq * 64;                     // first query row of this wave (and of its partner)
-    int qi[2];
-    qi[0] = q0w + r;
-    qi[1] = q0w + 32 + r;
+    const int q0w = qblk * RB + wq * RW;                      // first query row of this wave (and of its partner)
+    int qi[NZ];
+#pragma unroll
+    for (int z = 0; z < NZ; ++z) qi[z] = q0w + 32 * z + r;
 
     const T* __restrict__ qp = (const T*)p.q + ((size_t)bh * p.QL) * E;
     const char* __restrict__ kp = (const char*)((const T*)p.k + ((size_t)(b * p.KH + kvh) * p.KL) * E);
@@ -145,16 +163,16 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     // ---- number of kv tiles (workgroup) / live tiles (this wave): as in fa_fwd_w64.hpp ---------------------------------------------
     int n_tiles = (p.KL + BK - 1) / BK;
     int causal_q0 = 0x3fffffff;
-    int qlim[2] = {0x3fffffff, 0x3fffffff};
+    int qlim[2] = {0x3fffffff, 0x3fffffff};                  // (entry 1 unused at NZ = 1)
     if constexpr (kGeneral) {
         if (p.causal) {
-            int q_last = qblk * 256 + 255;
+            int q_last = qblk * RB + RB - 1;
             if (q_last > p.QL - 1) q_last = p.QL - 1;
             const int t_c = q_last / BK + 1;
             if (t_c < n_tiles) n_tiles = t_c;
             causal_q0 = q0w;
-            qlim[0] = qi[0];
-            qlim[1] = qi[1];
+#pragma unroll
+            for (int z = 0; z < NZ; ++z) qlim[z] = qi[z];
         }
         if (mp) {
             int* slot = reinterpret_cast<int*>(smem + MASK_OFF);
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     }
     int n_live = n_tiles;
     if (kGeneral && p.causal) {
-        const int t_w = (q0w + 63) / BK + 1;
+        const int t_w = (q0w + RW - 1) / BK + 1;
         if (t_w < n_live) n_live = t_w;
     }
 
@@ -217,18 +235,18 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     const float c2 = p.scale * kLog2e;
     // Q fragments: asm loads (invisible to hipcc's wait-count bookkeeping, like the LDS-DMA around them), valid behind the counted wait
     // below, which takes them as operands
-    f32x4 qw[2][KS];
+    f32x4 qw[NZ][KS];
 #pragma unroll
-    for (int z = 0; z < 2; ++z) {
+    for (int z = 0; z < NZ; ++z) {
         const int qc = qi[z] < p.QL ? qi[z] : p.QL - 1;
         const T* qrow = qp + (size_t)qc * E;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qw[z][ks]) : "v"(qrow + 16 * ks + 8 * h) : "memory");
     }
-    f32x16 oacc[2][EB];
-    f32x4 lacc[2];                                            // row sums: registers 0 / 1 of lanes 0..15 = queries lane, lane + 16 (SumMfma)
+    f32x16 oacc[NZ][EB];
+    f32x4 lacc[NZ];                                            // row sums: registers 0 / 1 of lanes 0..15 = queries lane, lane + 16 (SumMfma)
 #pragma unroll
-    for (int z = 0; z < 2; ++z) {
+    for (int z = 0; z < NZ; ++z) {
 #pragma unroll
         for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
@@ -259,12 +277,16 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     // K(grp) and Q landed (every wave's pieces: barrier); K(grp+2) and V(grp) -- the NJK + NJV pieces issued last -- stay in flight: the
     // loop's first counted wait (end of V(grp)) retires them, in time for M(grp+2).  The Q fragments pass through the statement.
     static_assert(KS == 4 && NJK + NJV == 4, "operand list / vmcnt literal below");
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier"
-                 : "+v"(qw[0][0]), "+v"(qw[0][1]), "+v"(qw[0][2]), "+v"(qw[0][3]), "+v"(qw[1][0]), "+v"(qw[1][1]), "+v"(qw[1][2]), "+v"(qw[1][3])
-                 :: "memory");
-    f32x16 qf[2];                                             // the 4 fragments (16-deep steps of E) of query block z, as one tuple
+    if constexpr (NZ == 2)
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier"
+                     : "+v"(qw[0][0]), "+v"(qw[0][1]), "+v"(qw[0][2]), "+v"(qw[0][3]), "+v"(qw[NZ - 1][0]), "+v"(qw[NZ - 1][1]), "+v"(qw[NZ - 1][2]),
+                       "+v"(qw[NZ - 1][3])
+                     :: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" : "+v"(qw[0][0]), "+v"(qw[0][1]), "+v"(qw[0][2]), "+v"(qw[0][3]) :: "memory");
+    f32x16 qf[NZ];                                            // the 4 fragments (16-deep steps of E) of query block z, as one tuple
 #pragma unroll
-    for (int z = 0; z < 2; ++z)
+    for (int z = 0; z < NZ; ++z)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -276,9 +298,9 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
 
     // the score tile S(t)^T: [z][key block].  V(t) packs P(t)^T IN PLACE: the 8 logits of 16-key step kk (registers 8 (kk & 1) .. + 7 of
     // sc[z][kk >> 1]) become 4 operand words in the first 4 of those registers.
-    f32x16 sc[2][KB];
+    f32x16 sc[NZ][KB];
 #pragma unroll
-    for (int z = 0; z < 2; ++z)
+    for (int z = 0; z < NZ; ++z)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -322,15 +344,30 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
 #define NNOP_DUO_PRIO_ARGS "", "", "", ""
 #endif
 #define NNOP_DUO_X(M, ...) M(__VA_ARGS__)
-    if constexpr (std::is_same<T, __bf16>::value) {
-        if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_MASKED, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
-        else asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_PLAIN, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
+    if constexpr (NZ == 2) {
+        if constexpr (std::is_same<T, __bf16>::value) {
+            if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_MASKED, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
+            else asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_PLAIN, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
+        } else {
+            if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_MASKED, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
+            else asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_PLAIN, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
+        }
     } else {
-        if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_MASKED, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
-        else asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_PLAIN, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
+        if constexpr (std::is_same<T, __bf16>::value) {
+            if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO1_LOOP_MASKED, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO1_OPERANDS);
+            else asm volatile(NNOP_DUO_X(NNOP_DUO1_LOOP_PLAIN, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO1_OPERANDS);
+        } else {
+            if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO1_LOOP_MASKED, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO1_OPERANDS);
+            else asm volatile(NNOP_DUO_X(NNOP_DUO1_LOOP_PLAIN, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO1_OPERANDS);
+        }
     }
     // (the loop keeps the true row max per lane half -- lane l ^ 32 holds the same query's other keys: combined here, once)
-    float m2[2] = {mstate[0], mstate[1]}, mt[2] = {half_swap_max(mstate[2]), half_swap_max(mstate[3])};
+    float m2[NZ], mt[NZ];
+#pragma unroll
+    for (int z = 0; z < NZ; ++z) {
+        m2[z] = mstate[z];
+        mt[z] = half_swap_max(mstate[2 + z]);
+    }
 #if NNOP_DUO_STAMP
     stamp[4] = __builtin_amdgcn_s_memtime();
     stamp[5] = __builtin_amdgcn_s_memrealtime();
@@ -347,7 +384,7 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     const char* const theirs = smem + (wave ^ 4) * (8192 + 3 * 256);
 #if NNOP_DUO_VALU_SUMS
     lacc[0][0] = half_swap_sum(lsum[0] + lsum[1]);            // (both lane halves: lane l ^ 32 holds the same query's other keys)
-    lacc[1][0] = half_swap_sum(lsum[2] + lsum[3]);
+    if constexpr (NZ == 2) lacc[NZ - 1][0] = half_swap_sum(lsum[2] + lsum[3]);
     auto row_sum = [&](const f32x4& l) -> float { return l[0]; };
 #else
     auto row_sum = [&](const f32x4& l) -> float {            // this lane's query r: lane r % 16, register r / 16
@@ -355,14 +392,15 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         return (r & 16) ? l1 : l0;
     };
 #endif
-    auto give = [&](auto givec) {
-        constexpr int ZG = decltype(givec)::value;
+    // what a wave gives away / keeps: at NZ = 2 a whole 32-row block z (all E columns), at NZ = 1 one 32-column half eb of its only block
+    auto give = [&](auto givec, auto eb0c, auto nebc) {
+        constexpr int ZG = decltype(givec)::value, EB0 = decltype(eb0c)::value, NEB = decltype(nebc)::value;
 #pragma unroll
-        for (int eb = 0; eb < EB; ++eb) {
+        for (int eb = EB0; eb < EB0 + NEB; ++eb) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const f32x4 w = {oacc[ZG][eb][4 * g4], oacc[ZG][eb][4 * g4 + 1], oacc[ZG][eb][4 * g4 + 2], oacc[ZG][eb][4 * g4 + 3]};
-                *reinterpret_cast<f32x4*>(mine + ((eb * 4 + g4) * 64 + lane) * 16) = w;
+                *reinterpret_cast<f32x4*>(mine + (((eb - EB0) * 4 + g4) * 64 + lane) * 16) = w;
             }
         }
         float* sm = reinterpret_cast<float*>(mine + 8192);
@@ -370,8 +408,9 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         sm[64 + lane] = m2[ZG];
         sm[128 + lane] = mt[ZG];
     };
-    auto take = [&](auto keepc) {
-        constexpr int ZK = decltype(keepc)::value;
+    auto take = [&](auto keepc, auto eb0c, auto nebc, auto statsc) {
+        constexpr int ZK = decltype(keepc)::value, EB0 = decltype(eb0c)::value, NEB = decltype(nebc)::value;
+        constexpr bool kStats = decltype(statsc)::value;
         const float* so_ = reinterpret_cast<const float*>(theirs + 8192);
         const float l_o = so_[lane], m_o = so_[64 + lane], mt_o = so_[128 + lane];
         const float l_m = row_sum(lacc[ZK]), m_m = m2[ZK];
@@ -384,12 +423,12 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         const float ai = a * inv, bi = bsc * inv;
         T* orow = (T*)p.o + ((size_t)bh * p.QL + (qi[ZK] < p.QL ? qi[ZK] : p.QL - 1)) * E;
 #pragma unroll
-        for (int eb = 0; eb < EB; ++eb) {
+        for (int eb = EB0; eb < EB0 + NEB; ++eb) {
             uint32_t pk[4][2];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 typedef T t4 __attribute__((ext_vector_type(4)));
-                const f32x4 ot = *reinterpret_cast<const f32x4*>(theirs + ((eb * 4 + g4) * 64 + lane) * 16);
+                const f32x4 ot = *reinterpret_cast<const f32x4*>(theirs + (((eb - EB0) * 4 + g4) * 64 + lane) * 16);
                 const f32x4 w = {oacc[ZK][eb][4 * g4] * ai + ot[0] * bi, oacc[ZK][eb][4 * g4 + 1] * ai + ot[1] * bi,
                                  oacc[ZK][eb][4 * g4 + 2] * ai + ot[2] * bi, oacc[ZK][eb][4 * g4 + 3] * ai + ot[3] * bi};
                 const u32x2 u = __builtin_bit_cast(u32x2, __builtin_convertvector(w, t4));
@@ -405,7 +444,7 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
                 if (qi[ZK] < p.QL) *reinterpret_cast<u32x4*>(orow + 32 * eb + 8 * g4 + 8 * h) = lo;
             }
         }
-        if (qi[ZK] < p.QL && h == 0) {
+        if (kStats && qi[ZK] < p.QL && h == 0) {
             // residual contract (src/attention.jl:128-129): ms = row max (natural-log units) rounded to T, ls relative to the ROUNDED ms
             const size_t so = (size_t)bh * p.QL + qi[ZK];
             const T m_t = from_f32<T>(mtt * kLn2);
@@ -416,12 +455,25 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
             ((T*)p.ls)[so] = from_f32<T>(l_out);
         }
     };
-    // group 0 keeps the rows of z = 0 and gives z = 1 away, group 1 the other way round
-    if (grp == 0) give(std::integral_constant<int, 1>{});
-    else give(std::integral_constant<int, 0>{});
-    __syncthreads();
-    if (grp == 0) take(std::integral_constant<int, 0>{});
-    else take(std::integral_constant<int, 1>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using IE = std::integral_constant<int, EB>;
+    if constexpr (NZ == 2) {
+        // group 0 keeps the rows of z = 0 and gives z = 1 away, group 1 the other way round
+        if (grp == 0) give(I1{}, I0{}, IE{});
+        else give(I0{}, I0{}, IE{});
+        __syncthreads();
+        if (grp == 0) take(I0{}, I0{}, IE{}, std::true_type{});
+        else take(I1{}, I0{}, IE{}, std::true_type{});
+    } else {
+        // both partners finish the same 32 rows: group 0 the columns 0..31 (and the residuals), group 1 the columns 32..63
+        static_assert(EB == 2, "the column split of the NZ = 1 epilogue");
+        if (grp == 0) give(I0{}, I1{}, I1{});
+        else give(I0{}, I0{}, I1{});
+        __syncthreads();
+        if (grp == 0) take(I0{}, I0{}, I1{}, std::true_type{});
+        else take(I0{}, I1{}, I1{}, std::false_type{});
+    }
 #if NNOP_DUO_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp[6] = __builtin_amdgcn_s_memtime();

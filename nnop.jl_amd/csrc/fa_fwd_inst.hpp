@@ -144,11 +144,12 @@ static int launch_fwd_w64(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
 }
 
 // two waves per SIMD in alternating phases (fa_fwd_duo.hpp): 8 waves, 256 query rows per workgroup, 16-bit types, E = 64
-template <typename T, int E, int MODE>
+// (NZ = 1: 32 rows per wave, 128 per workgroup -- fwd_duo_nz below)
+template <typename T, int E, int MODE, int NZ>
 static int launch_fwd_duo(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) {
     constexpr int lds = fa_fwd_duo_lds_bytes<T, E>(MODE != 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = fa_fwd_duo_kernel<T, E, MODE>;
+    auto kern = fa_fwd_duo_kernel<T, E, MODE, NZ>;
     static unsigned long long lds_done = 0;
     if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
     FwdParams p;
@@ -156,7 +157,7 @@ static int launch_fwd_duo(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     p.q = a.q; p.k = a.k; p.v = a.v; p.pair = nullptr; p.kpad = a.kpad;
     p.QL = d.ql; p.KL = d.kl; p.QH = d.qh; p.KH = d.kh; p.B = d.batch;
     p.causal = d.causal ? 1 : 0;
-    p.n_qblk = (d.ql + 255) / 256;
+    p.n_qblk = (d.ql + 128 * NZ - 1) / (128 * NZ);
     const long long n_wg = (long long)p.n_qblk * d.qh * d.batch;
     if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.n_wg = (int)n_wg;
@@ -178,6 +179,24 @@ static int launch_fwd_mode(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t 
 //   mode: 0 plain (every logit live), 1 masked (causal / key padding / ragged KL), 2 + pair bias
 static inline int fwd_mode(const nnop_fa_desc& d, bool has_pair, bool has_mask) {
     return has_pair ? 2 : ((d.causal || has_mask || (d.kl % 64) != 0) ? 1 : 0);
+}
+// Rows per wave of the two-waves-per-SIMD form: 64 (NZ = 2, 256-row workgroups), or 32 (NZ = 1: twice the workgroups at ~0.62 of the time
+// each -- every fragment read feeds one MFMA instead of two) where the 256-row blocks leave CUs idle.  Measured (MI355X, 256 CUs,
+// tools/duo_check.py with DUO_MODES=0,2,3, profiles/r04/nz1_sweep.log): equal-work blocks (plain, key padding) -- 32-row waves 1.35-1.6x
+// faster while the 128-row blocks still fit one round (L1024 H8 B4: 19.8 -> 14.0 us; L2048 H4 B4: 30.9 -> 21.4 us), +7 % where they turn
+// 2 rounds into 3 (L2048 H16 B3), 10-20 % SLOWER from there on; causal -- the finer blocks also even out the triangle: faster up to a
+// round and a half of 256-row blocks (L4096 H8 B2: 57.6 -> 45.1 us; L8192 H8 B1: 104.6 -> 79.6 us; L2048 H16 B3, 384 blocks: 55.3 ->
+// 47.3 us), 12 % slower from two rounds on.
+// Knob kTuneFwdDuo: 2 / 3 force NZ = 2 / 1.
+static inline int fwd_duo_nz(const nnop_fa_desc& d) {
+    const int duo = tune_get(kTuneFwdDuo);
+    if (duo == 2) return 2;
+    if (duo == 3) return 1;
+    const long long w2 = (long long)((d.ql + 255) / 256) * d.qh * d.batch, w1 = (long long)((d.ql + 127) / 128) * d.qh * d.batch;
+    const long long cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    if (d.causal) return 2 * w2 <= 3 * cus ? 1 : 2;
+    const long long r2 = (w2 + cus - 1) / cus, r1 = (w1 + cus - 1) / cus;
+    return 62 * r1 < 100 * r2 ? 1 : 2;
 }
 static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
     const bool b16 = d.dtype != NNOP_F32;
@@ -213,8 +232,10 @@ static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
         // Knob kTuneFwdDuo: 0 never, 1 wherever instantiated, auto = this rule.
         if (E == 64 && fits && tune_get(kTuneFwdExactScale) != 0) {
             const int duo = tune_get(kTuneFwdDuo);
-            const bool duo_pays = masked ? (d.kl >= 2048 || (d.kl >= 1024 && wg256 >= 128)) : d.kl >= 1024;
-            if (duo == 1 || (duo < 0 && w64 != 1 && duo_pays)) return kFormDuo;
+            // With 32-row waves (small grids, fwd_duo_nz) it wins from KL = 256 in every mode: 9-11 us against 13-16 us at KL = 512, 64-256
+            // 128-row blocks; 7.4-9.4 us against 9.6-10.4 us at KL = 256 (profiles/r04/nz1_small.log).
+            const bool duo_pays = fwd_duo_nz(d) == 1 ? d.kl >= 256 : (masked ? (d.kl >= 2048 || (d.kl >= 1024 && wg256 >= 128)) : d.kl >= 1024);
+            if (duo >= 1 || (duo < 0 && w64 != 1 && duo_pays)) return kFormDuo;
         }
         if (fits && (w64 == 1 || (w64 < 0 && pays))) return kFormW64;
     }
@@ -237,7 +258,10 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
         if (form == kFormW64) return mode == 0 ? launch_fwd_w64<T, E, 0, false>(d, a, s) : launch_fwd_w64<T, E, 1, false>(d, a, s);    // exact scale only
     }
     if constexpr (sizeof(T) == 2 && E == 64) {
-        if (form == kFormDuo) return mode == 0 ? launch_fwd_duo<T, E, 0>(d, a, s) : launch_fwd_duo<T, E, 1>(d, a, s);
+        if (form == kFormDuo) {
+            if (fwd_duo_nz(d) == 1) return mode == 0 ? launch_fwd_duo<T, E, 0, 1>(d, a, s) : launch_fwd_duo<T, E, 1, 1>(d, a, s);
+            return mode == 0 ? launch_fwd_duo<T, E, 0, 2>(d, a, s) : launch_fwd_duo<T, E, 1, 2>(d, a, s);
+        }
     }
     if constexpr (sizeof(T) == 2 && (E == 64 || E == 128)) {
         if (form == kFormW64) {

@@ -16,6 +16,13 @@ from util import assert_close, make_inputs, oracle_fwd
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[2, 3], ids=["rows64", "rows32"])
+def duo(request):
+    """knob fwd_duo: 2 forces the 64-rows-per-wave form (256-row workgroups), 3 the 32-row one (128-row workgroups, the loop without its
+    z = 1 half, the partners splitting the epilogue by columns); 1 = on, the launcher picks the rows per wave from the grid"""
+    return request.param
+
+
 def run(pkg, d, causal):
     o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=causal, kpad_mask=d["mask"])
     torch.cuda.synchronize()
@@ -39,27 +46,45 @@ def test_the_launcher_picks_the_form_where_it_measured_faster(pkg):
     f = pkg._lib.fwd_form
     assert f(mk()) == "fa_fwd_duo_kernel"                                   # C2, the headline shape
     assert f(mk(dtype=1, kl=1024, ql=1024)) == "fa_fwd_duo_kernel"          # plain mode from KL = 1024
-    assert f(mk(kl=512, ql=512)) != "fa_fwd_duo_kernel"                     # short key axes: prologue + merge dominate
+    assert f(mk(kl=512, ql=512, batch=64)) != "fa_fwd_duo_kernel"           # short key axes: prologue + merge dominate ...
+    assert f(mk(kl=512, ql=512)) == "fa_fwd_duo_kernel"                     # ... except on small grids, where 32-row waves spread the work
+    assert f(mk(kl=128, ql=128)) != "fa_fwd_duo_kernel"
     assert f(mk(causal=1, kl=2048, ql=2048)) == "fa_fwd_duo_kernel"         # masked mode from KL = 2048 ...
-    assert f(mk(causal=1, kl=1024, ql=1024, qh=2, kh=2, batch=2)) != "fa_fwd_duo_kernel"     # ... or KL = 1024 with >= 128 workgroups
+    assert f(mk(causal=1, kl=1024, ql=1024, qh=8, kh=8, batch=16)) == "fa_fwd_duo_kernel"    # ... or KL = 1024 with >= 128 workgroups
+    assert f(mk(kl=1000, ql=1024, qh=8, kh=8, batch=16)) != "fa_fwd_duo_kernel"             # (ragged KL: masked mode, 64-row waves)
     assert f(mk(emb=128)) == "fa_fwd_w64_kernel" and f(mk(dtype=0)) != "fa_fwd_duo_kernel"   # E = 64, 16-bit only
     assert f(mk(), True, False) != "fa_fwd_duo_kernel"                      # no pair-bias mode
 
 
+def test_rows_per_wave_follow_the_grid(pkg, dev, tune):
+    """knob 1 (on, rows per wave automatic) runs the same code as the forced choice the rule names: bitwise equal outputs.  256 CUs:
+    64 workgroups of 256 rows leave 3/4 of the chip idle -> 32-row waves (128 workgroups); 256 workgroups fill it -> 64-row waves"""
+    for B, want in ((1, 3), (4, 2)):
+        d = make_inputs(79, B, 16, 16, 1024, 1024, 64, "bf16", dev, need_do=False)
+        tune(fwd_duo=1)
+        a = run(pkg, d, False)
+        tune(fwd_duo=want)
+        b = run(pkg, d, False)
+        tune(fwd_duo=5 - want)
+        c = run(pkg, d, False)
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+        assert not torch.equal(a[0], c[0]) or B == 0          # (the other form sums in another order)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("QL,KL", [(256, 64), (300, 128), (64, 192), (511, 256), (512, 1024), (1024, 320), (257, 704), (40, 2048)])
-def test_plain(pkg, dev, tune, dt, QL, KL):
-    tune(fwd_duo=1)
+def test_plain(pkg, dev, tune, duo, dt, QL, KL):
+    tune(fwd_duo=duo)
     check(pkg, make_inputs(71, 2, 2, 2, QL, KL, 64, dt, dev, need_do=False), False, dt)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("L", [1, 63, 64, 65, 128, 255, 256, 257, 511, 777, 1024])
 @pytest.mark.parametrize("pad", [None, "ref"])
-def test_causal(pkg, dev, tune, dt, L, pad):
+def test_causal(pkg, dev, tune, duo, dt, L, pad):
     if pad == "ref" and L < 64:
         pytest.skip("the reference pattern masks the last 11 keys")
-    tune(fwd_duo=1)
+    tune(fwd_duo=duo)
     check(pkg, make_inputs(72, 2, 2, 2, L, L, 64, dt, dev, pad=pad, need_do=False), True, dt)
 
 
@@ -67,25 +92,25 @@ def test_causal(pkg, dev, tune, dt, L, pad):
 @pytest.mark.parametrize("pad", ["ref", "lens", "random"])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("QL,KL", [(700, 700), (300, 1000), (512, 448), (100, 37)])
-def test_key_padding_and_ragged(pkg, dev, tune, dt, pad, causal, QL, KL):
-    tune(fwd_duo=1)
+def test_key_padding_and_ragged(pkg, dev, tune, duo, dt, pad, causal, QL, KL):
+    tune(fwd_duo=duo)
     check(pkg, make_inputs(73, 3, 2, 2, QL, KL, 64, dt, dev, pad=pad, need_do=False), causal, dt)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("QH,KH", [(4, 1), (6, 2), (8, 2)])
 @pytest.mark.parametrize("causal", [False, True])
-def test_gqa(pkg, dev, tune, dt, QH, KH, causal):
-    tune(fwd_duo=1)
+def test_gqa(pkg, dev, tune, duo, dt, QH, KH, causal):
+    tune(fwd_duo=duo)
     check(pkg, make_inputs(74, 2, QH, KH, 515, 515, 64, dt, dev, need_do=False), causal, dt)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-def test_rows_and_batches_that_see_no_key(pkg, dev, tune, dt):
+def test_rows_and_batches_that_see_no_key(pkg, dev, tune, duo, dt):
     """a fully padded batch (every row: no visible key -> NaN rows, ms = -inf, as the naive formula gives) beside live ones, and
     causal rows whose only keys are padded (left padding): the exponent reference stays -inf, P = 0, and the merge of the two key
     groups must not turn (-inf) - (-inf) into a NaN for rows that DO have keys in the other group"""
-    tune(fwd_duo=1)
+    tune(fwd_duo=duo)
     d = make_inputs(81, 3, 2, 2, 384, 384, 64, dt, dev, need_do=False)
     m = np.ones((3, 384), dtype=bool)
     m[1, :] = False                                           # batch 1: nothing visible
@@ -106,10 +131,10 @@ def test_rows_and_batches_that_see_no_key(pkg, dev, tune, dt):
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("causal,pad", [(False, None), (True, "ref"), (False, "random")])
-def test_bitwise_reproducible_and_close_to_the_one_wave_form(pkg, dev, tune, dt, causal, pad):
+def test_bitwise_reproducible_and_close_to_the_one_wave_form(pkg, dev, tune, duo, dt, causal, pad):
     d = make_inputs(75, 2, 4, 2, 1100, 1100, 64, dt, dev, pad=pad, need_do=False)
     flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
-    tune(fwd_duo=1)
+    tune(fwd_duo=duo)
     outs = []
     for _ in range(5):
         flush.fill_(1)
@@ -127,7 +152,7 @@ def test_bitwise_reproducible_and_close_to_the_one_wave_form(pkg, dev, tune, dt,
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("spike_tiles", [(1,), (2, 5), (0, 3, 4, 9), (10,)])
-def test_forced_rise_of_the_deferred_max(pkg, dev, tune, dt, spike_tiles):
+def test_forced_rise_of_the_deferred_max(pkg, dev, tune, duo, dt, spike_tiles):
     """the rescale branch fires only when a row's max outgrows the exponent reference by 2^8 -- never on N(0,1) data after the
     first tile.  Plant keys that are strongly aligned with some queries at chosen kv tiles (even tiles: key group 0, odd: group 1) so
     that the running max jumps by far more than the threshold there, for a subset of the rows of a wave, and compare the FULL
@@ -145,7 +170,7 @@ def test_forced_rise_of_the_deferred_max(pkg, dev, tune, dt, spike_tiles):
         q[:, :, rows] = q[:, :, rows] * 0.2 + direction * 6.0
     tdt = d["q"].dtype
     d["q"], d["k"] = torch.tensor(q).to(tdt).to(dev), torch.tensor(k).to(tdt).to(dev)
-    tune(fwd_duo=1)
+    tune(fwd_duo=duo)
     check(pkg, d, False, dt)
     check(pkg, d, True, dt)
 
@@ -153,15 +178,15 @@ def test_forced_rise_of_the_deferred_max(pkg, dev, tune, dt, spike_tiles):
 @pytest.mark.parametrize("dt,causal,pad,QL,KL", [
     ("bf16", True, None, 2048, 2048), ("bf16", False, "random", 2048, 2048), ("f16", True, "lens", 2048 - 13, 2048 - 37),
     ("f16", False, "lens", 2048, 1024 + 37)])
-def test_persistent_block_list_is_bitwise_the_one_block_per_workgroup_launch(pkg, dev, tune, dt, causal, pad, QL, KL):
+def test_persistent_block_list_is_bitwise_the_one_block_per_workgroup_launch(pkg, dev, tune, duo, dt, causal, pad, QL, KL):
     """the persistent form (256 workgroups walking the static, balanced block list of fa_fwd_w64.hpp; knob fwd_persist) runs the same
     per-block code: outputs and residuals bitwise equal, every block visited exactly once; repeated persistent launches bitwise
     equal (the hand-over between two blocks is one barrier: rings, exchange buffer and validity words are rewritten behind it)"""
     d = make_inputs(77, 4, 16, 4, QL, KL, 64, dt, dev, pad=pad, need_do=False)        # B x QH = 64 columns: 8 per XCD, 2 steps of 32 blocks
     flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
-    tune(fwd_duo=1, fwd_persist=0)
+    tune(fwd_duo=duo, fwd_persist=0)
     ref = run(pkg, d, causal)
-    tune(fwd_duo=1, fwd_persist=1)
+    tune(fwd_duo=duo, fwd_persist=1)
     for _ in range(3):
         flush.fill_(1)
         got = run(pkg, d, causal)

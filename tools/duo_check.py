@@ -18,6 +18,7 @@ def timeit(f, n=20, warm=3):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+MODES = [int(x) for x in os.environ.get("DUO_MODES", "0,1").split(",")]     # knob values compared (2 / 3: rows per wave forced to 64 / 32)
 cfgs = sys.argv[1:] or ["bf16:64:4096:4:4:4:plain", "bf16:64:1024:4:2:2:causal", "f16:64:4096:16:4:4:lens", "f16:64:1000:4:4:2:ragged",
                         "bf16:64:2048:4:4:4:plain", "bf16:64:2048:4:4:4:causal", "bf16:64:4096:16:16:4:causal", "bf16:64:320:2:2:1:causal"]
 for c in cfgs:
@@ -33,7 +34,7 @@ for c in cfgs:
         mask = (torch.arange(KL)[None, :] < lens[:, None]).to(dev).contiguous()
     causal = mode == "causal"
     res, tm = {}, {}
-    for w in (0, 1):  # 0: the launcher without the duo form
+    for w in MODES:  # 0: the launcher without the duo form
         T("fwd_duo", w)
         o = torch.empty_like(q); ms = torch.empty(B, QH, L, dtype=DT[dt], device=dev); ls = torch.empty_like(ms)
         f = lambda: pkg.fa_fwd_into(o, ms, ls, q, k, v, causal=causal, kpad_mask=mask)
@@ -43,7 +44,9 @@ for c in cfgs:
         n = max(20, int(0.3e6 / (fl / 0.8e9 + 5)))
         tm[w] = timeit(f, n=n, warm=n)
     T("fwd_duo", -1)
-    d = [float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(res[1], res[0])]
-    nan = [bool(torch.isnan(a).any()) for a in res[1]]
-    nan0 = [bool(torch.isnan(a).any()) for a in res[0]]
-    print(f"{c:34s} diff o/ms/ls {d[0]:.2e} {d[1]:.2e} {d[2]:.2e} nan {nan} (other {nan0})  other {tm[0]:8.1f} us {fl/tm[0]/1e6:7.1f} TF | duo {tm[1]:8.1f} us {fl/tm[1]/1e6:7.1f} TF", flush=True)
+    m0, m1 = MODES[0], MODES[-1]
+    d = [float((torch.nan_to_num(a) - torch.nan_to_num(b)).abs().max() / torch.nan_to_num(b).abs().max().clamp_min(1e-30)) for a, b in zip(res[m1], res[m0])]
+    nan = [bool(torch.isnan(a).any()) for a in res[m1]]
+    nan0 = [bool(torch.isnan(a).any()) for a in res[m0]]
+    times = " | ".join(f"knob {w}: {tm[w]:8.1f} us {fl/tm[w]/1e6:7.1f} TF" for w in MODES)
+    print(f"{c:34s} diff o/ms/ls {d[0]:.2e} {d[1]:.2e} {d[2]:.2e} nan {nan} (first {nan0})  {times}", flush=True)

@@ -51,7 +51,7 @@ L = lambda z: 96 + 4 * z
 SEL = 104
 KA = lambda ks: 107 + ks            # ks = 1..3 -> v108..v110
 S = lambda z, kb: 112 + 32 * z + 16 * kb
-FR = lambda i: 176 + 4 * i if i < 4 else 224 + 4 * (i - 4)
+FR = lambda i: (176 + 4 * i if i < 4 else 224 + 4 * (i - 4)) if NZ == 2 else 144 + 4 * i      # NZ = 1: v[144:175], the z = 1 score tile's
 M2 = lambda z: 192 + z
 MT = lambda z: 194 + z
 KVO = lambda j: 196 + j
@@ -92,6 +92,17 @@ LS = lambda z, c: 248 + 2 * z + c
 SYNC = os.environ.get("NNOP_DUO_GEN_SYNC", "one")        # barriers per iteration: "two" (behind every phase) / "one" (group_loop)
 RING = int(os.environ.get("NNOP_DUO_GEN_RING", "4"))      # fragment ring slots (4 registers each): v[176:191] (+ v[224:...] beyond 4)
 PF = int(os.environ.get("NNOP_DUO_GEN_PF", "3"))          # fragments read ahead (< RING)
+# query blocks of 32 rows per wave.  2: the form described above (64 rows per wave, 256 per workgroup).  1: the SAME loop with every z = 1
+# register and instruction left out -- 32 rows per wave, 128 per workgroup: twice the workgroups for problems that cannot fill the chip
+# with 256-row blocks (every fragment then feeds ONE MFMA, so the fragment ring is deeper: it takes the registers of the z = 1 score tile).
+NZ = 2
+_RING2, _PF2 = RING, PF
+
+
+def set_nz(nz):
+    global NZ, RING, PF
+    NZ = nz
+    RING, PF = (_RING2, _PF2) if nz == 2 else (8, 6)
 
 # timing-only ablations (results WRONG by construction; never committed): NNOP_DUO_GEN_ABL bit mask
 #   1 no LDS-DMA in the loop   2 no row-max fillers   4 no exp / fma / convert in the vector phase   8 no MFMAs and no fragment reads
@@ -115,17 +126,20 @@ def v_rowmax():
     out = []
     for q in range(16):
         kb, i0 = q >> 3, 2 * (q & 7)
-        for z in range(2):
+        for z in range(NZ):
             a, b = S(z, kb) + i0, S(z, kb) + i0 + 1
             if q < 4:
                 out.append(f"v_max_f32 {vr(t(z, q))}, {vr(a)}, {vr(b)}")
             else:
                 out.append(f"v_max3_f32 {vr(t(z, q & 3))}, {vr(t(z, q & 3))}, {vr(a)}, {vr(b)}")
-    out += [f"v_max3_f32 {vr(t(z, 0))}, {vr(t(z, 0))}, {vr(t(z, 1))}, {vr(t(z, 2))}" for z in range(2)]
-    out += [f"v_max_f32 {vr(MX(z))}, {vr(t(z, 0))}, {vr(t(z, 3))}" for z in range(2)]
-    out += [f"v_mul_f32 {vr(MX(z))}, {sr(SC2)}, {vr(MX(z))}" for z in range(2)]
-    out += [f"v_max_f32 {vr(MT(z))}, {vr(MT(z))}, {vr(MX(z))}" for z in range(2)]
-    out += [f"v_cmp_gt_f32 vcc, {vr(MX(0))}, {vr(THR(0))}", f"v_cmp_gt_f32 {SM}, {vr(MX(1))}, {vr(THR(1))}", f"s_or_b64 {SM}, {SM}, vcc"]
+    out += [f"v_max3_f32 {vr(t(z, 0))}, {vr(t(z, 0))}, {vr(t(z, 1))}, {vr(t(z, 2))}" for z in range(NZ)]
+    out += [f"v_max_f32 {vr(MX(z))}, {vr(t(z, 0))}, {vr(t(z, 3))}" for z in range(NZ)]
+    out += [f"v_mul_f32 {vr(MX(z))}, {sr(SC2)}, {vr(MX(z))}" for z in range(NZ)]
+    out += [f"v_max_f32 {vr(MT(z))}, {vr(MT(z))}, {vr(MX(z))}" for z in range(NZ)]
+    if NZ == 2:
+        out += [f"v_cmp_gt_f32 vcc, {vr(MX(0))}, {vr(THR(0))}", f"v_cmp_gt_f32 {SM}, {vr(MX(1))}, {vr(THR(1))}", f"s_or_b64 {SM}, {SM}, vcc"]
+    else:
+        out += [f"v_cmp_gt_f32 {SM}, {vr(MX(0))}, {vr(THR(0))}", f"s_or_b64 {SM}, {SM}, {SM}"]       # (s_or_b64 sets SCC = result != 0)
     return out
 
 
@@ -138,7 +152,7 @@ def v_mask(g=0):
            f"s_lshl_b32 {sr(SA)}, {sr(ST)}, 6", f"s_add_i32 {sr(SA)}, {sr(SA)}, 63", f"s_cmp_gt_i32 {sr(SA)}, {sr(SCQ0)}",
            f"s_cbranch_scc0 L_maskdone{g}_%=", f"L_domask{g}_%=:", f"v_mov_b32 {vr(T0 + 10)}, 0xff800000"]
     lim, cm, sh, w = T0 + 4, T0 + 5, T0 + 6, T0 + 8        # w: 2 registers
-    for z in range(2):
+    for z in range(NZ):
         for kb in range(KB):
             # lim = qlim[z] - (64 t + 32 kb) - 4 h;  cm = lim < 0 ? 0 : 0xffffffff >> (31 - min(lim, 31))
             out += [f"s_lshl_b32 {sr(SA)}, {sr(ST)}, 6", f"s_add_i32 {sr(SA)}, {sr(SA)}, {32 * kb}",
@@ -215,7 +229,7 @@ def m_phase(qk, pv, masked):
         reads(p)
     if pv and SUMS == "mfma":
         for kk in range(2 * KB):
-            for z in range(2):
+            for z in range(NZ):
                 out.append(f"v_mfma_f32_16x16x32_@T@ {vr(L(z), 4)}, {vr(SEL, 4)}, {vr(PW(kk, z), 4)}, {vr(L(z), 4)}")
     mid = {}
     if DMA_AT.startswith("mmid") and len(stream) == NKF + NVF:
@@ -229,11 +243,11 @@ def m_phase(qk, pv, masked):
         slot = FR(p % RING)
         if kind == "V":
             kk, eb = divmod(idx, EB)
-            for z in range(2):
+            for z in range(NZ):
                 out.append(f"v_mfma_f32_32x32x16_@T@ {vr(O(z, eb), 16)}, {vr(slot, 4)}, {vr(PW(kk, z), 4)}, {vr(O(z, eb), 16)}")
         else:
             kb, ks = divmod(idx, KS)
-            for z in range(2):
+            for z in range(NZ):
                 c = "0" if ks == 0 else vr(S(z, kb), 16)
                 out.append(f"v_mfma_f32_32x32x16_@T@ {vr(S(z, kb), 16)}, {vr(slot, 4)}, {vr(Q(z, ks), 4)}, {c}")
         if p in mid:
@@ -265,27 +279,29 @@ def v_softmax(l1=4, l2=4, dma_at=()):
     out = []
     pieces = list(range(NJK + NJV - len(dma_at), NJK + NJV))
 
+    NEL = 32 * NZ
+
     def reg(n):
         c, j = n >> 3, n & 7
-        kk, z = c >> 1, c & 1
+        kk, z = (c >> 1, c & 1) if NZ == 2 else (c, 0)
         return S(z, kk >> 1) + 8 * (kk & 1) + j, z, kk, j
 
-    for step in range(64 + l1 + l2):
+    for step in range(NEL + l1 + l2):
         if step in dma_at:
             out += dma_piece(pieces.pop(0))
-        if step < 64:
+        if step < NEL:
             r, z, _, _ = reg(step)
             out.append(f"v_fma_f32 {vr(r)}, {vr(r)}, {sr(SC2)}, {vr(NM(z))}")
         e = step - l1
-        if 0 <= e < 64:
+        if 0 <= e < NEL:
             r, _, _, _ = reg(e)
             out.append(f"v_exp_f32 {vr(r)}, {vr(r)}")
         a = step - l1 - 2
-        if SUMS == "valu" and 0 <= a < 64:
+        if SUMS == "valu" and 0 <= a < NEL:
             r, z, _, j = reg(a)
             out.append(f"v_add_f32 {vr(LS(z, j & 1))}, {vr(LS(z, j & 1))}, {vr(r)}")
         m = step - l1 - l2
-        if 0 <= m < 64 and (m & 1):
+        if 0 <= m < NEL and (m & 1):
             r, z, kk, j = reg(m)
             out.append(f"v_cvt_pk_@T@_f32 {vr(PW(kk, z) + (j >> 1))}, {vr(r - 1)}, {vr(r)}")
     return out
@@ -296,14 +312,14 @@ def rescale():
     accumulated at the old one (O, l) exactly once.  Before the first tile O and l are zero: scaled by 0, harmless."""
     out = ["s_nop 15"] * 8           # the PV MFMAs of the last matrix phase have written O (fa_fwd_w64.hpp: 128 idle cycles)
     # the row maxima of both lane halves (lane l <-> l ^ 32): swap the upper half of one copy with the lower half of the other
-    out += [f"v_mov_b32 {vr(T0 + 8 + z)}, {vr(MX(z))}" for z in range(2)] + ["s_nop 1"]
-    out += [f"v_permlane32_swap_b32 {vr(MX(z))}, {vr(T0 + 8 + z)}" for z in range(2)]
-    out += [f"v_max_f32 {vr(MX(z))}, {vr(MX(z))}, {vr(T0 + 8 + z)}" for z in range(2)]
+    out += [f"v_mov_b32 {vr(T0 + 8 + z)}, {vr(MX(z))}" for z in range(NZ)] + ["s_nop 1"]
+    out += [f"v_permlane32_swap_b32 {vr(MX(z))}, {vr(T0 + 8 + z)}" for z in range(NZ)]
+    out += [f"v_max_f32 {vr(MX(z))}, {vr(MX(z))}, {vr(T0 + 8 + z)}" for z in range(NZ)]
     a0, a1, lane = T0, T0 + 1, T0 + 2
     out += [f"v_mbcnt_lo_u32_b32 {vr(lane)}, -1, 0", f"v_mbcnt_hi_u32_b32 {vr(lane)}, -1, {vr(lane)}", f"v_and_b32 {vr(a0)}, 15, {vr(lane)}",
             f"v_lshlrev_b32 {vr(a0)}, 2, {vr(a0)}", f"v_add_u32 {vr(a1)}, 64, {vr(a0)}"]
     thr, mn, al, b0, b1 = T0 + 3, T0 + 4, T0 + 5, T0 + 6, T0 + 7
-    for z in range(2):
+    for z in range(NZ):
         out += [f"v_cmp_gt_f32 vcc, {vr(MX(z))}, {vr(THR(z))}",
                 f"v_cndmask_b32 {vr(mn)}, {vr(M2(z))}, {vr(MX(z))}, vcc",
                 f"v_sub_f32 {vr(al)}, {vr(M2(z))}, {vr(mn)}", f"v_exp_f32 {vr(al)}, {vr(al)}", "s_nop 0",
@@ -391,7 +407,7 @@ def loop(masked, prof=False):
     own in front of the statement).  Half-steps h = 0 .. n_tiles + 1: group g runs M(t) at h = t for t = g (mod 2) and V(t) at h = t + 1;
     PV(t) happens in M(t + 2)."""
     out = []
-    out += [f"v_mov_b32 {vr(NM(z))}, 0" for z in range(2)] + [f"v_mov_b32 {vr(THR(z))}, 0xff800000" for z in range(2)]     # m2 = -inf
+    out += [f"v_mov_b32 {vr(NM(z))}, 0" for z in range(NZ)] + [f"v_mov_b32 {vr(THR(z))}, 0xff800000" for z in range(NZ)]     # m2 = -inf
     if prof:                         # s71..s75: cycles in M, at the barrier behind it, in V, in the DMA wait, at the barrier behind that
         out += ["s_memtime s[68:69]", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s70, s68"] + [f"s_mov_b32 s{a}, 0" for a in range(71, 76)]
     if SYNC == "two":
@@ -498,10 +514,18 @@ def render():
              f"#define NNOP_DUO_SLOTS_PER_GROUP {SLOTS}      // ring slots per key group and ring (where the DMA batch is issued decides)\n"
              f"#define NNOP_DUO_VALU_SUMS {1 if SUMS == 'valu' else 0}            // 1: row sums by v_add_f32 in the vector phase (4 chains in v[248:251])\n"
              f"#define NNOP_DUO_SYNC_ONE {1 if SYNC == 'one' else 0}             // 1: one barrier per iteration, no barrier of group 1 in front of the statement\n"]
-    for masked in (False, True):
-        check_stream(loop(masked))
+    for nz in (2, 1):
+        set_nz(nz)
+        for masked in (False, True):
+            check_stream(loop(masked))
+    set_nz(2)
     parts.append(as_macro("NNOP_DUO_LOOP_PLAIN", loop(False)))
     parts.append(as_macro("NNOP_DUO_LOOP_MASKED", loop(True)))
+    set_nz(1)
+    parts.append("// the same loop with ONE 32-row query block per wave (128-row workgroups): the z = 1 registers and instructions left out\n")
+    parts.append(as_macro("NNOP_DUO1_LOOP_PLAIN", loop(False)))
+    parts.append(as_macro("NNOP_DUO1_LOOP_MASKED", loop(True)))
+    set_nz(2)
     parts.append("// profile builds (make DEV=1 VAR=-DNNOP_DUO_STAMP=1): the same loops with s_memtime ticks; the five accumulators leave in v[224:228]\n"
                  "#ifdef NNOP_DEV_BUILD")
     parts.append(as_macro("NNOP_DUO_LOOP_PLAIN_PROF", loop(False, True)))
