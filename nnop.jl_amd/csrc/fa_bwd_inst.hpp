@@ -60,12 +60,12 @@ static int launch_dq(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
 }
 
 // The one-wave-per-SIMD form (fa_bwd_w64.hpp): KIND = kBwdDKDV / kBwdDQ
-template <typename T, int E, int KIND, int MODE>
+template <typename T, int E, int KIND, int MODE, int NARROW = 0>
 static int launch_bwd_w64(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
-    using SH = BwdW64Shape<E, KIND>;
-    constexpr int lds = fa_bwd_w64_lds_bytes<T, E, KIND>(MODE != 0);
+    using SH = BwdW64Shape<E, KIND, NARROW>;
+    constexpr int lds = fa_bwd_w64_lds_bytes<T, E, KIND, NARROW>(MODE != 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = fa_bwd_w64_kernel<T, E, KIND, MODE>;
+    auto kern = fa_bwd_w64_kernel<T, E, KIND, MODE, NARROW>;
     static unsigned long long lds_done = 0;
     if (ensure_dynamic_lds(kern, lds, &lds_done) != NNOP_OK) return NNOP_ERR_HIP;
     BwdParams pk = p;
@@ -110,6 +110,19 @@ static inline bool bwd_w64_ok(const nnop_fa_desc& d, int kind) {
         return true;
     }
     return (long long)d.kl * rb < (1LL << 32) && d.kl <= 64 * kMaxMaskTiles;
+}
+// The narrow shape of that form (BwdW64Shape NARROW: 32 stationary rows per wave, 128-row workgroups) where the 256-row blocks of a pass
+// leave CUs idle -- the forward's rule (fa_fwd_inst.hpp fwd_duo_nz).  Knob kTuneBwdNarrow: 0 never, 1 wherever instantiated.
+static inline bool bwd_w64_narrow(const nnop_fa_desc& d, int kind) {
+    if (d.emb != 64 && d.emb != 128) return false;
+    const int knob = tune_get(kTuneBwdNarrow);
+    if (knob >= 0) return knob != 0;
+    const int len = kind == kBwdDQ ? d.ql : d.kl, hd = kind == kBwdDQ ? d.qh : d.kh;
+    const long long w2 = (long long)((len + 255) / 256) * hd * d.batch, w1 = (long long)((len + 127) / 128) * hd * d.batch;
+    const long long cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    if (d.causal) return 2 * w2 <= 3 * cus;
+    const long long r2 = (w2 + cus - 1) / cus, r1 = (w1 + cus - 1) / cus;
+    return 62 * r1 < 100 * r2;
 }
 // bit 0: dK/dV runs fa_bwd_w64_kernel, bit 1: dQ does (knob kTuneBwdW64: 0 never, 1 both, 2 dK/dV only, 3 dQ only, 4 both with the
 // preprocess launch kept, auto = both)
@@ -183,7 +196,12 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         int st = NNOP_OK;
         bool done = false;
         if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128 || E == 256)) {
-            if (w64_kv) { st = launch_bwd_w64<T, E, kBwdDKDV, MODE>(d, p, s); done = true; }
+            if (w64_kv) {
+                if constexpr (E != 256) {
+                    if (bwd_w64_narrow(d, kBwdDKDV)) { st = launch_bwd_w64<T, E, kBwdDKDV, MODE, 1>(d, p, s); done = true; }
+                }
+                if (!done) { st = launch_bwd_w64<T, E, kBwdDKDV, MODE>(d, p, s); done = true; }
+            }
         }
         if constexpr (C::kBig7) if (!done) {
             // 8 waves double-buffered where K lives in registers (64 KiB of V images + 2 x 32 KiB of tiles), else 7 single-buffered
@@ -206,9 +224,18 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
         if constexpr (MODE <= 1 && sizeof(T) == 2 && (E == 64 || E == 128 || E == 256)) {
             // plain mode needs whole steps of keys; a ragged KL takes the masked kernel
             if (w64_q) {
-                if (MODE == 0 && (d.kl & 31) != 0) st = launch_bwd_w64<T, E, kBwdDQ, 1>(d, p, s);
-                else st = launch_bwd_w64<T, E, kBwdDQ, MODE>(d, p, s);
-                done = true;
+                if constexpr (E != 256) {
+                    if (bwd_w64_narrow(d, kBwdDQ)) {                                  // (64 streamed keys per step there)
+                        if (MODE == 0 && (d.kl & 63) != 0) st = launch_bwd_w64<T, E, kBwdDQ, 1, 1>(d, p, s);
+                        else st = launch_bwd_w64<T, E, kBwdDQ, MODE, 1>(d, p, s);
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    if (MODE == 0 && (d.kl & 31) != 0) st = launch_bwd_w64<T, E, kBwdDQ, 1>(d, p, s);
+                    else st = launch_bwd_w64<T, E, kBwdDQ, MODE>(d, p, s);
+                    done = true;
+                }
             }
         }
         if constexpr (C::kBig7) if (!done) {

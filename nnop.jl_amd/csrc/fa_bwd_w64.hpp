@@ -93,8 +93,11 @@ template <typename T, int E> struct DualImg {
 };
 
 // ---- shapes -------------------------------------------------------------------------------------------------------------------
-template <int E, int KIND> struct BwdW64Shape {
+// NARROW: 32 stationary rows per wave x 64 streamed rows per step (1 x 2) at E = 64 / 128 -- 128-row workgroups, for launches whose
+// 256-row blocks leave CUs idle (fa_bwd_inst.hpp bwd_w64_narrow): every streamed fragment feeds one MFMA instead of two.
+template <int E, int KIND, int NARROW = 0> struct BwdW64Shape {
     static constexpr bool kDQ = KIND == kBwdDQ;
+    static_assert(!NARROW || E == 64 || E == 128, "narrow form: E = 64 / 128");
     // E = 256: one block each way (the accumulator file holds 128 accumulator + 128 fragment registers of ONE 32-row block), and the
     // dK/dV pass runs as NSPLIT = 2 launches-in-one: each workgroup keeps full-E K / V fragments (S and dP contract over all of E)
     // but only half of the dK^T / dV^T accumulators -- 6 product-units instead of 4, spill-free.
@@ -102,8 +105,8 @@ template <int E, int KIND> struct BwdW64Shape {
     // traffic per MFMA of the 1 x 2 shape it replaces -- although their dK^T / dV^T accumulators are the whole accumulator file (256):
     // the K fragments live in the arch VGPRs (64) and the V fragments are read from an LDS image of the workgroup's V rows, as a
     // second fragment stream beside the dO rows.
-    static constexpr bool kVLds = !kDQ && E == 128;
-    static constexpr int ZS = E == 256 ? 1 : ((kDQ || E == 64 || kVLds) ? 2 : 1);       // stationary 32-row blocks per wave
+    static constexpr bool kVLds = !kDQ && E == 128 && !NARROW;
+    static constexpr int ZS = (E == 256 || NARROW) ? 1 : ((kDQ || E == 64 || kVLds) ? 2 : 1);       // stationary 32-row blocks per wave
     static constexpr int ZT = E == 256 ? 1 : 2 / ZS;                           // streamed 32-row blocks per step
     static constexpr int NSPLIT = (!kDQ && E == 256) ? 2 : 1;
     static constexpr int NYP = kDQ ? 1 : 2;                   // Y products
@@ -132,8 +135,8 @@ template <int E, int KIND> struct BwdW64Shape {
     static_assert(IMG % 4096 == 0 && NJ >= 1 && NJ <= 4, "four waves x NJ pieces = one image; 12-bit immediate");
     static_assert(SLOT % (RB > 256 ? RB : 256) == 0, "XOR-addressed fragment reads: slot bases aligned to a row / 256 bytes");
 };
-template <typename T, int E, int KIND> constexpr int fa_bwd_w64_lds_bytes(bool masked) {
-    using SH = BwdW64Shape<E, KIND>;
+template <typename T, int E, int KIND, int NARROW = 0> constexpr int fa_bwd_w64_lds_bytes(bool masked) {
+    using SH = BwdW64Shape<E, KIND, NARROW>;
     return SH::NS * SH::SLOT + SH::VIMG + (masked ? (SH::kDQ ? 16 + 8 * kMaxMaskTiles : 16) : 0);
 }
 
@@ -147,8 +150,8 @@ template <typename T, int E, int KIND> constexpr int fa_bwd_w64_lds_bytes(bool m
 // the smallest per-gap budget for which a greedy in-order fill places everything (prices: tools/w64_gaps.py, calibrated on
 // tools/ubench/gapcost.hip).  One constraint: no B item in gap 0 -- the dP tiles are written by the last MFMAs of the previous
 // iteration, and a VALU read needs two MFMA slots of distance (tools/audit_w64.py checks the generated code).
-template <int E, int KIND, bool MASKED, int LAG, int PF> struct BwdW64Plan {
-    using SH = BwdW64Shape<E, KIND>;
+template <int E, int KIND, bool MASKED, int LAG, int PF, int NARROW = 0> struct BwdW64Plan {
+    using SH = BwdW64Shape<E, KIND, NARROW>;
     static constexpr int NSLOT = SH::NSLOT, NEL = SH::NEL, NITEM = NEL + NEL + NEL / 2;
     static constexpr int BAR_SLOT = (SH::NFY - PF) * SH::ZS;  // the barrier opens this slot (all column reads of Y are issued)
     int kind[NITEM] = {};                                     // 0 A, 1 B, 2 C
@@ -249,9 +252,9 @@ template <typename T, int EB> NNOP_DEV void store_acc_row16(T* rowp, f32x16 (&ac
     }
 }
 
-template <typename T, int E, int KIND, int MODE>
+template <typename T, int E, int KIND, int MODE, int NARROW = 0>
 __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_arg) {
-    using SH = BwdW64Shape<E, KIND>;
+    using SH = BwdW64Shape<E, KIND, NARROW>;
     using frag_t = typename Elem<T>::frag;
     using Img = DualImg<T, E>;
     using MM = MfmaAsm<T>;
@@ -690,21 +693,24 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_ar
         // dQ: register row = key t0 + lr + 4 h, lane = query: keep iff the key is valid and key <= query (causal)
         uint64_t vword_next = 0;
         auto vword_fetch = [&](int u) { const int w = (u * RT) >> 6; vword_next = vbits[w < kMaxMaskTiles ? w : kMaxMaskTiles - 1]; };
-        auto vword_take = [&](int u) -> uint32_t {
+        // (one bit per streamed key of a step: 32, or 64 in the narrow shape -- RT keys per step)
+        using vword_t = std::conditional_t<(kDQ && RT == 64), uint64_t, uint32_t>;
+        constexpr vword_t kAllValid = ~(vword_t)0;
+        auto vword_take = [&](int u) -> vword_t {
             const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(vword_next >> 32)) << 32) |
                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)vword_next);
-            return (uint32_t)(w >> ((u * RT) & 63));
+            return (vword_t)(w >> ((u * RT) & 63));
         };
-        auto apply_mask = [&](f32x16 (&s)[ZS][ZT], int t0, uint32_t valid) {
+        auto apply_mask = [&](f32x16 (&s)[ZS][ZT], int t0, vword_t valid) {
 #pragma unroll
             for (int zs = 0; zs < ZS; ++zs)
 #pragma unroll
                 for (int zt = 0; zt < ZT; ++zt) {
                     uint32_t m;
                     if constexpr (kDQ) {
-                        const int lim = (p.causal ? sidx[zs] : 0x3fffffff) - t0 - 4 * h;
+                        const int lim = (p.causal ? sidx[zs] : 0x3fffffff) - t0 - 32 * zt - 4 * h;
                         const uint32_t cm = lim >= 31 ? ~0u : (lim < 0 ? 0u : ((2u << lim) - 1u));
-                        m = (valid >> (4 * h)) & cm;
+                        m = (uint32_t)(valid >> (32 * zt + 4 * h)) & cm;
                     } else {
                         const int lim = sidx[zs] - t0 - 32 * zt - 4 * h;                 // keep iff lr >= lim
                         m = lim <= 0 ? ~0u : (lim >= 32 ? 0u : ~((1u << lim) - 1u));
@@ -719,8 +725,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_ar
         // first streamed row of compute step u (dK/dV: a query index inside its head; dQ: a key index)
         int c_s = 0;                                                        // step inside the head, of the step being exponentiated
         auto step_t0 = [&]() -> int { return (u0 + c_s) * RT; };
-        auto step_needs_mask = [&](int t0, uint32_t valid) -> bool {
-            if constexpr (kDQ) return valid != ~0u || (p.causal && t0 + RT - 1 > s0w);
+        auto step_needs_mask = [&](int t0, vword_t valid) -> bool {
+            if constexpr (kDQ) return valid != kAllValid || (p.causal && t0 + RT - 1 > s0w);
             else return p.causal && t0 < s0w + SW - 1;
         };
 
@@ -753,6 +759,10 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_ar
             asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
                          : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b1[0][4]), "+a"(b1[0][5]), "+a"(b1[0][6]), "+a"(b1[0][7]),
                            "+a"(b2[0][0]), "+a"(b2[0][1]), "+a"(b2[0][2]), "+a"(b2[0][3]), "+a"(b2[0][4]), "+a"(b2[0][5]), "+a"(b2[0][6]), "+a"(b2[0][7])
+                         : [nfl] "n"(2 * NPB) : "memory");
+        } else if constexpr (KS == 4 && ZS == 1) {
+            asm volatile("s_waitcnt vmcnt(%c[nfl])\n\ts_barrier"
+                         : "+a"(b1[0][0]), "+a"(b1[0][1]), "+a"(b1[0][2]), "+a"(b1[0][3]), "+a"(b2[0][0]), "+a"(b2[0][1]), "+a"(b2[0][2]), "+a"(b2[0][3])
                          : [nfl] "n"(2 * NPB) : "memory");
         } else {
             static_assert(KS == 4 && ZS == 2, "");
@@ -820,7 +830,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_ar
         if constexpr (kBases) set_cbase(sY);
 
         // ---- one iteration: Y(u-1) on the fragments `fp`, X(u+1) into (sn, dn), element-wise work of step u: (sc, dc) -> `fw` -----
-        using Plan = BwdW64Plan<E, KIND, kGeneral, LAG, PF>;
+        using Plan = BwdW64Plan<E, KIND, kGeneral, LAG, PF, NARROW>;
         auto iteration = [&](int u, f32x16 (&sc)[ZS][ZT], f32x16 (&dc)[ZS][ZT], f32x16 (&sn)[ZS][ZT], f32x16 (&dn)[ZS][ZT],
                              u32x4 (&fw)[NYP][ZS][2 * ZT], u32x4 (&fp)[NYP][ZS][2 * ZT]) {
             constexpr Plan plan = Plan::make();
@@ -829,7 +839,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_w64_kernel(const BwdParams p_ar
             // masked mode: the tile of step u is masked before it is exponentiated (rare: diagonal blocks, ragged / padded tiles)
             if constexpr (kGeneral) {
                 const int t0 = step_t0();
-                uint32_t valid = ~0u;
+                vword_t valid = kAllValid;
                 if constexpr (kDQ) {
                     valid = vword_take(u);
                     vword_fetch(u + 1);

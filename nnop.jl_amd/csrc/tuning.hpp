@@ -26,6 +26,7 @@ enum TuneKey {
     kTuneBwdPersist,     // NNOP_BWD_PERSIST the same for the one-wave-per-SIMD backward kernels
     kTuneFwdDuo,         // NNOP_FWD_DUO     two-waves-per-SIMD alternating-phase forward (fa_fwd_duo.hpp, 16-bit E = 64): 0 never, 1 wherever instantiated
     kTuneFwdPersistAsc,  // NNOP_FWD_PERSIST_ASC persistent forward: q-blocks of a column ascending (light first: 1) / descending (0)
+    kTuneBwdNarrow,      // NNOP_BWD_NARROW  one-wave-per-SIMD backward with 32 stationary rows per wave (128-row workgroups): 0 never, 1 wherever instantiated
     kTuneCount
 };
 

@@ -12,6 +12,15 @@ from util import make_inputs, oracle_bwd, assert_close
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["rows64", "rows32"])
+def shape(request, tune):
+    """both wave shapes of the kernel template on every case of this file: 64 stationary rows per wave (256-row workgroups) and the
+    narrow one (BwdW64Shape NARROW: 32 rows per wave, 64 streamed rows per step, 128-row workgroups) that the launcher picks where
+    256-row blocks would leave CUs idle (knob bwd_narrow; tests below for the rule itself)"""
+    tune(bwd_narrow=request.param)
+    return request.param
+
+
 def run_bwd(pkg, d, causal):
     o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], None, causal=causal, kpad_mask=d["mask"])
     dq, dk, dv, dp = pkg.grad_flash_attention(d["do"], o, ms, ls, d["q"], d["k"], d["v"], None, causal=causal, kpad_mask=d["mask"])
@@ -224,3 +233,15 @@ def test_persistent_block_list_is_bitwise_the_one_block_per_workgroup_launch(pkg
         got = bwd()
         for a, b_, name in zip(ref, got, ("dq", "dk", "dv")):
             assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b_.float())), name
+
+
+def test_narrow_shape_follows_the_grid(pkg, dev, tune):
+    """the launcher's own choice (knob at automatic) is bitwise the forced shape its rule names: 256 CUs -- 32 blocks of 256 rows leave
+    7/8 of the chip idle -> 32-row waves; 512 blocks -> 64-row waves; causal: narrow up to a round and a half of 256-row blocks"""
+    for B, causal, want in ((1, False, 1), (16, False, 0), (8, True, 1), (16, True, 0)):
+        d = make_inputs(97, B, 8, 8, 1024, 1024, 64, "bf16", dev)
+        tune(bwd_narrow=-1)
+        a = run_bwd(pkg, d, causal)
+        tune(bwd_narrow=want)
+        b = run_bwd(pkg, d, causal)
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), (B, causal)
