@@ -48,9 +48,12 @@ def test_schedule_of_the_generated_loop_stays_balanced():
     # the backward kernels (csrc/fa_bwd_w64.hpp; round 3, measured 49.8 / 50.6 cycles per algorithmic MFMA at E = 64, 38.2 in the dQ pass at E = 128): one compile
     r = subprocess.run([sys.executable, gaps, "IDF16b", "--bwd"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    got = {(int(m.group(1)), int(m.group(2))): float(m.group(3))
-           for m in re.finditer(r"Li(\d+)ELi(\d)ELi0E\w*: .*? ([\d.]+) per MFMA", r.stdout)}
-    lim = {(64, 0): 45.0, (64, 1): 49.5, (128, 0): 40.0, (128, 1): 39.5, (256, 0): 45.0, (256, 1): 44.0}        # (E, kind: 0 dK/dV, 1 dQ), plain mode
+    got = {(int(m.group(1)), int(m.group(2)), int(m.group(3))): float(m.group(4))
+           for m in re.finditer(r"Li(\d+)ELi(\d)ELi0ELi(\d)E\w*: .*? ([\d.]+) per MFMA", r.stdout)}
+    # (E, kind: 0 dK/dV, 1 dQ, narrow shape), plain mode.  The narrow shape (32 stationary rows per wave: one MFMA per fragment read) pays
+    # 20-26 % more issue per MFMA -- it is launched only where it doubles the number of busy SIMDs.
+    lim = {(64, 0, 0): 45.0, (64, 1, 0): 49.5, (128, 0, 0): 40.0, (128, 1, 0): 39.5, (256, 0, 0): 45.0, (256, 1, 0): 44.0,
+           (64, 0, 1): 53.5, (64, 1, 1): 59.5, (128, 0, 1): 44.5, (128, 1, 1): 47.0}
     assert set(got) == set(lim), r.stdout
     assert all(got[k] <= lim[k] for k in lim), got
 
@@ -73,4 +76,4 @@ def test_scratch_only_where_it_is_known_and_never_in_the_e256_kernels():
             else:
                 assert scratch == 0 and spills == 0, (name, scratch, spills)
             seen += 1
-    assert seen == 10 + 12
+    assert seen == 10 + 12 + 8
