@@ -59,12 +59,8 @@ def test_phase_structure_of_the_loop():
 
 
 def test_compiled_kernels_allocate_within_the_loops_register_map():
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "fwd.s")
-        r = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-S", "--cuda-device-only",
-                            "-o", out, os.path.join(CSRC, "fa_fwd_bf16.hip")], capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-2000:]
-        text = open(out).read()
+    from audit_w64 import compile_asm                        # (the library's flags; shares its cache with tests/test_w64_codegen.py)
+    text = compile_asm("fa_fwd_bf16.hip", [])
     got = {}
     for m in re.finditer(r"\.set _ZN4nnop17fa_fwd_duo_kernelIDF16bLi64ELi(\d)ELi(\d)EEEvNS_9FwdParamsE\.(num_vgpr|num_agpr|private_seg_size), (\d+)", text):
         got[(int(m.group(1)), int(m.group(2)), m.group(3))] = int(m.group(4))

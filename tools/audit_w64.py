@@ -28,12 +28,24 @@ CSRC = os.path.join(ROOT, "nnop.jl_amd", "csrc")
 
 
 def compile_asm(src, extra):
-    out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
+    """device assembly of one translation unit.  Cached under the temp dir by a hash of every source in csrc/ and the flags: the audit,
+    the schedule model (w64_gaps.py) and the codegen tests all look at the same few compiles (a minute each)."""
+    import glob, hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.h*")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(CSRC, src)]):
+        hsh.update(f.encode()); hsh.update(open(f, "rb").read())
+    hsh.update(" ".join(extra).encode())
+    cache = os.path.join(tempfile.gettempdir(), "nnop_asm_cache")
+    os.makedirs(cache, exist_ok=True)
+    hit = os.path.join(cache, f"{src}.{hsh.hexdigest()[:24]}.s")
+    if os.path.exists(hit):
+        return open(hit).read()
+    out = tempfile.NamedTemporaryFile(suffix=".s", delete=False, dir=cache).name
     cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "--cuda-device-only", "-S",
            os.path.join(CSRC, src), "-o", out] + extra
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = open(out).read()
-    os.unlink(out)
+    os.replace(out, hit)
     return text
 
 
