@@ -89,9 +89,27 @@ namespace nnop {
           "v221", "v222", "v223", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70",    \
           "s71", "s72", "s73", "s74", "s75", "s76", "s77"
 
+// E = 128 (NZ = 1): O^T = 4 column blocks, Q = 8 fragments; v[100:103] more K fragment addresses, v[180:182] more DMA offsets
+#define NNOP_DUO128_OPERANDS                                                                                                     \
+    "+{v[0:15]}"(oacc[0][0]), "+{v[16:31]}"(oacc[0][1]), "+{v[32:47]}"(oacc[0][EB - 2]), "+{v[48:63]}"(oacc[0][EB - 1]),                  \
+        "+{v[64:79]}"(qf[0]), "+{v[80:95]}"(qf[NQT - 1]), "+{v[96:99]}"(lacc[0]), "+{v[104:107]}"(sel), "+{v[112:127]}"(sc[0][0]),        \
+        "+{v[128:143]}"(sc[0][1]), "+{v[192:195]}"(mstate), [st] "+s"(s_t), [ska] "+s"(s_ka), [skb] "+s"(s_kb), [skc] "+s"(s_kc),         \
+        [sva] "+s"(s_va), [svb] "+s"(s_vb), [svc] "+s"(s_vc)                                                                            \
+        : "{v[196:203]}"(vconst), [sh] "s"(s_h), [snlive] "s"(s_nlive), [slast] "s"(s_last), [sc2] "s"(c2), [scq0] "s"(s_cq0),            \
+          [svbits] "s"(s_vbits), [krs] "s"(krs), [vrs] "s"(vrs)                                                                       \
+        : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v108", "v109", "v110", "v111", "v144", "v145", "v146", "v147", "v148",  \
+          "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164",   \
+          "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180",   \
+          "v181", "v182", "v183", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216",   \
+          "v217", "v218", "v219", "v220", "v221", "v222", "v223", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",     \
+          "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77"
+
 constexpr int kDuoXchgBytes = 8 * (8192 + 3 * 256);          // epilogue exchange: per wave 32 fp32 per lane + (l, m2, mt)
+// ring slots per key group and ring / barriers per iteration: properties of the generated loop of an embedding dim (fa_fwd_duo_asm.inc)
+template <int E> constexpr int duo_slots_per_group() { return E == 128 ? NNOP_DUO128_SLOTS_PER_GROUP : NNOP_DUO_SLOTS_PER_GROUP; }
+template <int E> constexpr bool duo_sync_one() { return (E == 128 ? NNOP_DUO128_SYNC_ONE : NNOP_DUO_SYNC_ONE) != 0; }
 template <typename T, int E> constexpr int fa_fwd_duo_lds_bytes(bool masked) {
-    constexpr int ring = 2 * NNOP_DUO_SLOTS_PER_GROUP * (RowImg<T, E>::bytes(64) + ColImg<T, E>::bytes(64));
+    constexpr int ring = 2 * duo_slots_per_group<E>() * (RowImg<T, E>::bytes(64) + ColImg<T, E>::bytes(64));
     return (ring > kDuoXchgBytes ? ring : kDuoXchgBytes) + (masked ? 16 + 8 * kMaxMaskTiles : 0);
 }
 
@@ -100,13 +118,13 @@ template <typename T, int E> constexpr int fa_fwd_duo_lds_bytes(bool masked) {
 // every fragment then feeds one MFMA and the per-iteration overheads are paid per 32 rows: ~8 % more cycles per row).
 template <typename T, int E, int MODE, int NZ = 2>
 __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
-    static_assert(sizeof(T) == 2 && E == 64 && (NZ == 1 || NZ == 2), "16-bit element types, E = 64");
+    static_assert(sizeof(T) == 2 && ((E == 64 && (NZ == 1 || NZ == 2)) || (E == 128 && NZ == 1)), "16-bit element types; E = 64, or E = 128 with 32-row waves");
     constexpr int RW = 32 * NZ, RB = 4 * RW;                  // query rows per wave / per workgroup
     using frag_t = typename Elem<T>::frag;
     using KImg   = RowImg<T, E>;
     using VImg   = ColImg<T, E>;
     constexpr bool kGeneral = MODE != 0;
-    constexpr int BK = 64, KB = 2, KS = E / 16, EB = E / 32, NS = 2 * NNOP_DUO_SLOTS_PER_GROUP;
+    constexpr int BK = 64, KB = 2, KS = E / 16, EB = E / 32, NS = 2 * duo_slots_per_group<E>();
     constexpr int KBYTES = KImg::bytes(BK), VBYTES = VImg::bytes(BK);
     constexpr int RING = NS * (KBYTES + VBYTES);
     constexpr int MASK_OFF = RING > kDuoXchgBytes ? RING : kDuoXchgBytes;
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     // kB = slot of K(t+2); kC = the free slot, target of K(t+4) (with 2 slots per group: kA again, and the batch is then issued behind the
     // barrier that closes M(t)).  vA = slot of V(t-2), read in M(t); vB = slot of V(t); vC = free, target of V(t+2).  The group's slots
     // rotate (A, B, C) <- (B, C, A) per iteration.
-    constexpr int SPG = NNOP_DUO_SLOTS_PER_GROUP;
+    constexpr int SPG = duo_slots_per_group<E>();
     const uint32_t kA = kring + wave_off_k + (uint32_t)(SPG * grp) * KBYTES, kB = kA + KBYTES, kC = kA + (SPG - 1) * KBYTES;
     const uint32_t vA = vring + wave_off_v + (uint32_t)(SPG * grp) * VBYTES, vB = vA + VBYTES, vC = vA + (SPG - 1) * VBYTES;
     // ragged KL: rows of the last tile past KL are outside the descriptor's range -- the ring must not hold non-finite garbage there
@@ -276,21 +294,27 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     const uint32_t v_lane = (uint32_t)VImg::lane_base(lane) - wave_off_v;
     // K(grp) and Q landed (every wave's pieces: barrier); K(grp+2) and V(grp) -- the NJK + NJV pieces issued last -- stay in flight: the
     // loop's first counted wait (end of V(grp)) retires them, in time for M(grp+2).  The Q fragments pass through the statement.
-    static_assert(KS == 4 && NJK + NJV == 4, "operand list / vmcnt literal below");
-    if constexpr (NZ == 2)
-        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier"
+    if constexpr (E == 128)
+        asm volatile("s_waitcnt vmcnt(%c[n])\n\ts_barrier"
+                     : "+v"(qw[0][0]), "+v"(qw[0][1]), "+v"(qw[0][2]), "+v"(qw[0][3]), "+v"(qw[0][KS - 4]), "+v"(qw[0][KS - 3]), "+v"(qw[0][KS - 2]),
+                       "+v"(qw[0][KS - 1])
+                     : [n] "n"(NJK + NJV) : "memory");
+    else if constexpr (NZ == 2)
+        asm volatile("s_waitcnt vmcnt(%c[n])\n\ts_barrier"
                      : "+v"(qw[0][0]), "+v"(qw[0][1]), "+v"(qw[0][2]), "+v"(qw[0][3]), "+v"(qw[NZ - 1][0]), "+v"(qw[NZ - 1][1]), "+v"(qw[NZ - 1][2]),
                        "+v"(qw[NZ - 1][3])
-                     :: "memory");
+                     : [n] "n"(NJK + NJV) : "memory");
     else
-        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" : "+v"(qw[0][0]), "+v"(qw[0][1]), "+v"(qw[0][2]), "+v"(qw[0][3]) :: "memory");
-    f32x16 qf[NZ];                                            // the 4 fragments (16-deep steps of E) of query block z, as one tuple
+        asm volatile("s_waitcnt vmcnt(%c[n])\n\ts_barrier" : "+v"(qw[0][0]), "+v"(qw[0][1]), "+v"(qw[0][2]), "+v"(qw[0][3]) : [n] "n"(NJK + NJV) : "memory");
+    // the fragments (16-deep steps of E) as 16-register tuples: v[64:79], v[80:95] = query blocks 0, 1 at E = 64 / steps 0-3, 4-7 at E = 128
+    constexpr int NQT = NZ * KS / 4;
+    f32x16 qf[NQT];
 #pragma unroll
     for (int z = 0; z < NZ; ++z)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) qf[z][4 * ks + i] = qw[z][ks][i];
+            for (int i = 0; i < 4; ++i) qf[(z * KS + ks) / 4][4 * (ks & 3) + i] = qw[z][ks][i];
 #if NNOP_DUO_STAMP
     stamp[2] = __builtin_amdgcn_s_memtime();
     stamp[3] = __builtin_amdgcn_s_memrealtime();
@@ -328,9 +352,9 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
 #if NNOP_DUO_PRIO == 2
     if (grp) __builtin_amdgcn_s_setprio(1);
 #endif
-#if !NNOP_DUO_SYNC_ONE
-    if (grp) asm volatile("s_barrier" ::: "memory");          // half-step 0: group 1 has nothing to do yet
-#endif
+    if constexpr (!duo_sync_one<E>()) {
+        if (grp) asm volatile("s_barrier" ::: "memory");      // half-step 0: group 1 has nothing to do yet
+    }
 #if NNOP_DUO_STAMP
 #define NNOP_DUO_LOOP_MASKED NNOP_DUO_LOOP_MASKED_PROF
 #define NNOP_DUO_LOOP_PLAIN NNOP_DUO_LOOP_PLAIN_PROF
@@ -351,6 +375,14 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         } else {
             if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_MASKED, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
             else asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_PLAIN, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
+        }
+    } else if constexpr (E == 128) {
+        if constexpr (std::is_same<T, __bf16>::value) {
+            if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO128_LOOP_MASKED, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO128_OPERANDS);
+            else asm volatile(NNOP_DUO_X(NNOP_DUO128_LOOP_PLAIN, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO128_OPERANDS);
+        } else {
+            if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO128_LOOP_MASKED, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO128_OPERANDS);
+            else asm volatile(NNOP_DUO_X(NNOP_DUO128_LOOP_PLAIN, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO128_OPERANDS);
         }
     } else {
         if constexpr (std::is_same<T, __bf16>::value) {
@@ -466,13 +498,13 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
         if (grp == 0) take(I0{}, I0{}, IE{}, std::true_type{});
         else take(I1{}, I0{}, IE{}, std::true_type{});
     } else {
-        // both partners finish the same 32 rows: group 0 the columns 0..31 (and the residuals), group 1 the columns 32..63
-        static_assert(EB == 2, "the column split of the NZ = 1 epilogue");
-        if (grp == 0) give(I0{}, I1{}, I1{});
-        else give(I0{}, I0{}, I1{});
+        // both partners finish the same 32 rows: group 0 the first half of the columns (and the residuals), group 1 the second
+        using IH = std::integral_constant<int, EB / 2>;       // (E = 64: 1 block of 32 columns each, E = 128: 2)
+        if (grp == 0) give(I0{}, IH{}, IH{});
+        else give(I0{}, I0{}, IH{});
         __syncthreads();
-        if (grp == 0) take(I0{}, I0{}, I1{}, std::true_type{});
-        else take(I0{}, I1{}, I1{}, std::false_type{});
+        if (grp == 0) take(I0{}, I0{}, IH{}, std::true_type{});
+        else take(I0{}, IH{}, IH{}, std::false_type{});
     }
 #if NNOP_DUO_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -230,6 +230,19 @@ static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
         // every grid size (32 .. 4096 workgroups), 3-20 % faster in masked mode from KL = 2048 (from KL = 1024 with >= 128
         // workgroups); slower below (KL = 512: +10..19 %: the prologue holds three tiles and the epilogue merges two key groups).
         // Knob kTuneFwdDuo: 0 never, 1 wherever instantiated, auto = this rule.
+        if (E == 128 && fits && tune_get(kTuneFwdExactScale) != 0) {
+            // E = 128: the two-wave form exists with 32-row waves only (fa_fwd_duo.hpp: 128-row workgroups whose partner waves split the
+            // keys).  Per tile it is 10-14 % SLOWER than the one-wave form (every fragment read feeds one MFMA: LDS-bound; C3 4388 vs
+            // 3972 us), but it has twice the workgroups and halves a block's critical path: measured (profiles/r04/duo128_sweep.log)
+            // 1.1-1.3x faster while the 128-row blocks fit one round (L2048 H8 B2: 42.9 -> 36.5 us), 1.3-1.7x under a causal mask
+            // (L2048 H8 B2: 54.0 -> 33.4 us; L4096 H8 B1: 97.2 -> 57.8; L8192 H8 B1: 189 -> 135), and still ahead up to two rounds in
+            // masked mode from KL = 2048 (causal L2048 H8 B4: 56.6 -> 44.3; lens L2048 B4: 68.8 -> 62.4).  KL = 256: a tie.
+            const int duo = tune_get(kTuneFwdDuo);
+            const long long w1 = (long long)((d.ql + 127) / 128) * d.qh * d.batch;
+            const long long cus = device_cu_count() > 0 ? device_cu_count() : 256;
+            const bool duo_pays = d.kl >= 512 && (w1 <= cus || (masked && d.kl >= 2048 && w1 <= 2 * cus));
+            if (duo >= 1 || (duo < 0 && w64 != 1 && duo_pays)) return kFormDuo;
+        }
         if (E == 64 && fits && tune_get(kTuneFwdExactScale) != 0) {
             const int duo = tune_get(kTuneFwdDuo);
             // With 32-row waves (small grids, fwd_duo_nz) it wins from KL = 256 in every mode: 9-11 us against 13-16 us at KL = 512, 64-256
@@ -256,6 +269,9 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     const long long wg256 = (long long)((d.ql + 255) / 256) * d.qh * d.batch;
     if constexpr (sizeof(T) == 2 && E == 256) {
         if (form == kFormW64) return mode == 0 ? launch_fwd_w64<T, E, 0, false>(d, a, s) : launch_fwd_w64<T, E, 1, false>(d, a, s);    // exact scale only
+    }
+    if constexpr (sizeof(T) == 2 && E == 128) {
+        if (form == kFormDuo) return mode == 0 ? launch_fwd_duo<T, E, 0, 1>(d, a, s) : launch_fwd_duo<T, E, 1, 1>(d, a, s);
     }
     if constexpr (sizeof(T) == 2 && E == 64) {
         if (form == kFormDuo) {

@@ -16,11 +16,18 @@ from util import assert_close, make_inputs, oracle_fwd
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[2, 3], ids=["rows64", "rows32"])
+class Shape:
+    def __init__(self, knob, E):
+        self.knob, self.E = knob, E
+
+
+@pytest.fixture(params=[(2, 64), (3, 64), (1, 128)], ids=["rows64", "rows32", "e128"])
 def duo(request):
-    """knob fwd_duo: 2 forces the 64-rows-per-wave form (256-row workgroups), 3 the 32-row one (128-row workgroups, the loop without its
-    z = 1 half, the partners splitting the epilogue by columns); 1 = on, the launcher picks the rows per wave from the grid"""
-    return request.param
+    """the three generated loops.  E = 64, knob fwd_duo: 2 forces the 64-rows-per-wave form (256-row workgroups), 3 the 32-row one
+    (128-row workgroups, the loop without its z = 1 half, the partners splitting the epilogue by columns); 1 = on, the launcher picks
+    the rows per wave from the grid.  E = 128: 32-row waves only (16 KiB tiles: 2 ring slots per key group, the LDS-DMA batch in the
+    vector phase, a barrier behind every phase)"""
+    return Shape(*request.param)
 
 
 def run(pkg, d, causal):
@@ -54,6 +61,9 @@ def test_the_launcher_picks_the_form_where_it_measured_faster(pkg):
     assert f(mk(kl=1000, ql=1024, qh=8, kh=8, batch=16)) != "fa_fwd_duo_kernel"             # (ragged KL: masked mode, 64-row waves)
     assert f(mk(emb=128)) == "fa_fwd_w64_kernel" and f(mk(dtype=0)) != "fa_fwd_duo_kernel"   # E = 64, 16-bit only
     assert f(mk(), True, False) != "fa_fwd_duo_kernel"                      # no pair-bias mode
+    # E = 128 (32-row waves only, slower per tile): while the 128-row blocks fit one round; two rounds in masked mode from KL = 2048
+    assert f(mk(emb=128, ql=2048, kl=2048)) == "fa_fwd_duo_kernel" and f(mk(emb=128, ql=2048, kl=2048, batch=8)) == "fa_fwd_w64_kernel"
+    assert f(mk(emb=128, causal=1, qh=8, kh=8, batch=2)) == "fa_fwd_duo_kernel" and f(mk(emb=128, causal=1, qh=8, kh=8, batch=4)) == "fa_fwd_w64_kernel"
 
 
 def test_rows_per_wave_follow_the_grid(pkg, dev, tune):
@@ -74,8 +84,8 @@ def test_rows_per_wave_follow_the_grid(pkg, dev, tune):
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("QL,KL", [(256, 64), (300, 128), (64, 192), (511, 256), (512, 1024), (1024, 320), (257, 704), (40, 2048)])
 def test_plain(pkg, dev, tune, duo, dt, QL, KL):
-    tune(fwd_duo=duo)
-    check(pkg, make_inputs(71, 2, 2, 2, QL, KL, 64, dt, dev, need_do=False), False, dt)
+    tune(fwd_duo=duo.knob)
+    check(pkg, make_inputs(71, 2, 2, 2, QL, KL, duo.E, dt, dev, need_do=False), False, dt)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
@@ -84,8 +94,8 @@ def test_plain(pkg, dev, tune, duo, dt, QL, KL):
 def test_causal(pkg, dev, tune, duo, dt, L, pad):
     if pad == "ref" and L < 64:
         pytest.skip("the reference pattern masks the last 11 keys")
-    tune(fwd_duo=duo)
-    check(pkg, make_inputs(72, 2, 2, 2, L, L, 64, dt, dev, pad=pad, need_do=False), True, dt)
+    tune(fwd_duo=duo.knob)
+    check(pkg, make_inputs(72, 2, 2, 2, L, L, duo.E, dt, dev, pad=pad, need_do=False), True, dt)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
@@ -93,16 +103,16 @@ def test_causal(pkg, dev, tune, duo, dt, L, pad):
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("QL,KL", [(700, 700), (300, 1000), (512, 448), (100, 37)])
 def test_key_padding_and_ragged(pkg, dev, tune, duo, dt, pad, causal, QL, KL):
-    tune(fwd_duo=duo)
-    check(pkg, make_inputs(73, 3, 2, 2, QL, KL, 64, dt, dev, pad=pad, need_do=False), causal, dt)
+    tune(fwd_duo=duo.knob)
+    check(pkg, make_inputs(73, 3, 2, 2, QL, KL, duo.E, dt, dev, pad=pad, need_do=False), causal, dt)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("QH,KH", [(4, 1), (6, 2), (8, 2)])
 @pytest.mark.parametrize("causal", [False, True])
 def test_gqa(pkg, dev, tune, duo, dt, QH, KH, causal):
-    tune(fwd_duo=duo)
-    check(pkg, make_inputs(74, 2, QH, KH, 515, 515, 64, dt, dev, need_do=False), causal, dt)
+    tune(fwd_duo=duo.knob)
+    check(pkg, make_inputs(74, 2, QH, KH, 515, 515, duo.E, dt, dev, need_do=False), causal, dt)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
@@ -110,8 +120,8 @@ def test_rows_and_batches_that_see_no_key(pkg, dev, tune, duo, dt):
     """a fully padded batch (every row: no visible key -> NaN rows, ms = -inf, as the naive formula gives) beside live ones, and
     causal rows whose only keys are padded (left padding): the exponent reference stays -inf, P = 0, and the merge of the two key
     groups must not turn (-inf) - (-inf) into a NaN for rows that DO have keys in the other group"""
-    tune(fwd_duo=duo)
-    d = make_inputs(81, 3, 2, 2, 384, 384, 64, dt, dev, need_do=False)
+    tune(fwd_duo=duo.knob)
+    d = make_inputs(81, 3, 2, 2, 384, 384, duo.E, dt, dev, need_do=False)
     m = np.ones((3, 384), dtype=bool)
     m[1, :] = False                                           # batch 1: nothing visible
     m[2, :100] = False                                        # batch 2: left padding -- causal rows 0..99 see nothing
@@ -132,9 +142,9 @@ def test_rows_and_batches_that_see_no_key(pkg, dev, tune, duo, dt):
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("causal,pad", [(False, None), (True, "ref"), (False, "random")])
 def test_bitwise_reproducible_and_close_to_the_one_wave_form(pkg, dev, tune, duo, dt, causal, pad):
-    d = make_inputs(75, 2, 4, 2, 1100, 1100, 64, dt, dev, pad=pad, need_do=False)
+    d = make_inputs(75, 2, 4, 2, 1100, 1100, duo.E, dt, dev, pad=pad, need_do=False)
     flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
-    tune(fwd_duo=duo)
+    tune(fwd_duo=duo.knob)
     outs = []
     for _ in range(5):
         flush.fill_(1)
@@ -158,7 +168,7 @@ def test_forced_rise_of_the_deferred_max(pkg, dev, tune, duo, dt, spike_tiles):
     that the running max jumps by far more than the threshold there, for a subset of the rows of a wave, and compare the FULL
     output with the oracle (the exact fp32 scale holds the standard tolerance at any logit size)."""
     rng = np.random.default_rng(76)
-    B, H, L, E = 1, 2, 704, 64
+    B, H, L, E = 1, 2, 704, duo.E
     d = make_inputs(77, B, H, H, L, L, E, dt, dev, need_do=False)
     q, k = d["q"].float().cpu().numpy(), d["k"].float().cpu().numpy()
     for i, t in enumerate(spike_tiles):
@@ -170,7 +180,7 @@ def test_forced_rise_of_the_deferred_max(pkg, dev, tune, duo, dt, spike_tiles):
         q[:, :, rows] = q[:, :, rows] * 0.2 + direction * 6.0
     tdt = d["q"].dtype
     d["q"], d["k"] = torch.tensor(q).to(tdt).to(dev), torch.tensor(k).to(tdt).to(dev)
-    tune(fwd_duo=duo)
+    tune(fwd_duo=duo.knob)
     check(pkg, d, False, dt)
     check(pkg, d, True, dt)
 
@@ -182,11 +192,11 @@ def test_persistent_block_list_is_bitwise_the_one_block_per_workgroup_launch(pkg
     """the persistent form (256 workgroups walking the static, balanced block list of fa_fwd_w64.hpp; knob fwd_persist) runs the same
     per-block code: outputs and residuals bitwise equal, every block visited exactly once; repeated persistent launches bitwise
     equal (the hand-over between two blocks is one barrier: rings, exchange buffer and validity words are rewritten behind it)"""
-    d = make_inputs(77, 4, 16, 4, QL, KL, 64, dt, dev, pad=pad, need_do=False)        # B x QH = 64 columns: 8 per XCD, 2 steps of 32 blocks
+    d = make_inputs(77, 4, 16, 4, QL, KL, duo.E, dt, dev, pad=pad, need_do=False)        # B x QH = 64 columns: 8 per XCD, 2 steps of 32 blocks
     flush = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
-    tune(fwd_duo=duo, fwd_persist=0)
+    tune(fwd_duo=duo.knob, fwd_persist=0)
     ref = run(pkg, d, causal)
-    tune(fwd_duo=duo, fwd_persist=1)
+    tune(fwd_duo=duo.knob, fwd_persist=1)
     for _ in range(3):
         flush.fill_(1)
         got = run(pkg, d, causal)

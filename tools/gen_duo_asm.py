@@ -49,12 +49,12 @@ O = lambda z, eb: 16 * (2 * z + eb)
 Q = lambda z, ks: 64 + 16 * z + 4 * ks
 L = lambda z: 96 + 4 * z
 SEL = 104
-KA = lambda ks: 107 + ks            # ks = 1..3 -> v108..v110
+KA = lambda ks: 107 + ks if ks < 4 else 96 + ks      # ks = 1..3 -> v108..v110; E = 128: ks = 4..7 -> v100..v103
 S = lambda z, kb: 112 + 32 * z + 16 * kb
 FR = lambda i: (176 + 4 * i if i < 4 else 224 + 4 * (i - 4)) if NZ == 2 else 144 + 4 * i      # NZ = 1: v[144:175], the z = 1 score tile's
 M2 = lambda z: 192 + z
 MT = lambda z: 194 + z
-KVO = lambda j: 196 + j
+KVO = lambda j: 196 + j if E == 64 else (196 if j == 0 else 179 + j)      # E = 128: pieces 1..3 in v[180:182], derived in front of the loop
 VVO, KLANE, VLANE = 198, 199, 200
 QLIM = lambda z: 201 + z
 H4 = 203
@@ -73,9 +73,11 @@ SVAL = "s[62:63]"
 SM = "s[64:65]"
 SNEED = 77
 
+E = 64
 KS, KB, EB, NKF, NVF = 4, 2, 2, 8, 8
 NJK, NJV = 2, 2
 TILE_SHIFT = 13                      # one 64-key tile of E = 64 16-bit elements = 8 KiB
+ROWB = 128                           # bytes of a K row in its LDS image
 
 
 # where the LDS-DMA batch K(t+4), V(t+2) is issued: "mhead" / "mtail" / "msplit" = first / last thing (half and half) of the matrix phase M(t), into the group's
@@ -84,12 +86,14 @@ TILE_SHIFT = 13                      # one 64-key tile of E = 64 16-bit elements
 # vector phase is the longer one, and an LDS-DMA instruction stalls the issuing wave ~60 cycles WITHOUT using the vector port.
 DMA_AT = os.environ.get("NNOP_DUO_GEN_DMA", "mtail")
 SLOTS = 2 if DMA_AT == "v" else 3                        # ("mmid" / "mmidq": between the MFMA pairs of the matrix phase)
+_DMA64, _SLOTS64 = DMA_AT, SLOTS
 
 # row sums of P: "mfma" = 8 v_mfma_f32_16x16x32 per tile in the matrix phase (selector operand), "valu" = 64 v_add_f32 per tile in the
 # vector phase (4 chains in v[248:251]).  Measured (profiles/r04/duo_sums.log): see DESIGN.md section 4.1d.
 SUMS = os.environ.get("NNOP_DUO_GEN_SUMS", "mfma")
 LS = lambda z, c: 248 + 2 * z + c
 SYNC = os.environ.get("NNOP_DUO_GEN_SYNC", "one")        # barriers per iteration: "two" (behind every phase) / "one" (group_loop)
+_SYNC64 = SYNC
 RING = int(os.environ.get("NNOP_DUO_GEN_RING", "4"))      # fragment ring slots (4 registers each): v[176:191] (+ v[224:...] beyond 4)
 PF = int(os.environ.get("NNOP_DUO_GEN_PF", "3"))          # fragments read ahead (< RING)
 # query blocks of 32 rows per wave.  2: the form described above (64 rows per wave, 256 per workgroup).  1: the SAME loop with every z = 1
@@ -99,10 +103,20 @@ NZ = 2
 _RING2, _PF2 = RING, PF
 
 
-def set_nz(nz):
-    global NZ, RING, PF
-    NZ = nz
+def set_nz(nz, e=64):
+    """the loop's shape: nz 32-row query blocks per wave at embedding dim e.  E = 128 (nz = 1 only: O^T alone is 64 registers): tiles of
+    16 KiB, so 2 ring slots per key group and ring (128 KiB of LDS) -- the DMA batch then goes behind the barrier that closes the matrix
+    phase whose slots it overwrites, i.e. into the vector phase, with a barrier behind EVERY phase (the matrix phase is the longer one
+    there: 36 MFMAs against 32 logits per lane, so the vector-phase wave has the idle issue slots the 8 LDS-DMA pieces cost)."""
+    global NZ, RING, PF, E, KS, EB, NKF, NVF, NJK, NJV, TILE_SHIFT, ROWB, DMA_AT, SLOTS, SYNC
+    assert e == 64 or (e == 128 and nz == 1)
+    NZ, E = nz, e
     RING, PF = (_RING2, _PF2) if nz == 2 else (8, 6)
+    KS, EB = e // 16, e // 32
+    NKF, NVF = KB * KS, 4 * EB
+    NJK = NJV = e // 32
+    TILE_SHIFT, ROWB = (13, 128) if e == 64 else (14, 256)
+    DMA_AT, SLOTS, SYNC = (_DMA64, _SLOTS64, _SYNC64) if e == 64 else ("v", 2, "two")
 
 # timing-only ablations (results WRONG by construction; never committed): NNOP_DUO_GEN_ABL bit mask
 #   1 no LDS-DMA in the loop   2 no row-max fillers   4 no exp / fma / convert in the vector phase   8 no MFMAs and no fragment reads
@@ -204,13 +218,13 @@ def m_phase(qk, pv, masked):
         slot = FR(p % RING)
         if kind == "V":
             kk, eb = divmod(idx, EB)
-            out.append(f"ds_read_b64_tr_b16 {vr(slot, 2)}, {vr(VIMG)} offset:{(8 * kk + eb) * 256}")
-            out.append(f"ds_read_b64_tr_b16 {vr(slot + 2, 2)}, {vr(VIMG)} offset:{(8 * kk + 4 + eb) * 256}")
+            out.append(f"ds_read_b64_tr_b16 {vr(slot, 2)}, {vr(VIMG)} offset:{(4 * kk * EB + eb) * 256}")
+            out.append(f"ds_read_b64_tr_b16 {vr(slot + 2, 2)}, {vr(VIMG)} offset:{((4 * kk + 2) * EB + eb) * 256}")
             lds_issued += 2
         else:
             kb, ks = divmod(idx, KS)
             addr = vr(KIMG) if ks == 0 else vr(KA(ks))
-            out.append(f"ds_read_b128 {vr(slot, 4)}, {addr} offset:{kb * 32 * 128}")
+            out.append(f"ds_read_b128 {vr(slot, 4)}, {addr} offset:{kb * 32 * ROWB}")
             lds_issued += 1
         last_read[p] = lds_issued - 1
 
@@ -378,7 +392,9 @@ def group_loop(g, masked, prof):
         out += ["s_waitcnt lgkmcnt(0)"] + v_mask(g)
     out += ([f"s_mov_b64 {SM}, 0", "s_cmp_lg_u32 0, 0"] if ABL & 2 else v_rowmax())
     out += [f"s_cbranch_scc1 {L('rescale')}", L("rescdone") + ":"]          # (s_or_b64 sets SCC = result != 0)
-    out += ([] if ABL & 4 else v_softmax(dma_at=(16, 40) if DMA_AT == "v" else ())) + ["@VP0@"]
+    # ("v": the first two pieces lead the phase, the others go between the element-wise steps)
+    spread = ((16, 40) if NZ == 2 else (12, 28)) if NJK + NJV == 4 else (4, 10, 16, 22, 28, 34)
+    out += ([] if ABL & 4 else v_softmax(dma_at=spread if DMA_AT == "v" else ())) + ["@VP0@"]
     if DMA_AT == "v":                # a wave without the tile keeps the group's DMA schedule
         out += [f"s_branch {L('vdone2')}", L("vdone") + ":"]
         for d in range(NJK + NJV):
@@ -408,6 +424,10 @@ def loop(masked, prof=False):
     PV(t) happens in M(t + 2)."""
     out = []
     out += [f"v_mov_b32 {vr(NM(z))}, 0" for z in range(NZ)] + [f"v_mov_b32 {vr(THR(z))}, 0xff800000" for z in range(NZ)]     # m2 = -inf
+    if E == 128:
+        # DMA source offsets of this wave's K pieces 1..3: piece j covers image rows 4 j .. 4 j + 3 of the wave's 16 and the image XORs a
+        # row's 16-byte chunks with row & 15, so offset j = offset 0 with chunk bits 2..3 flipped by j
+        out += [f"v_xor_b32 {vr(KVO(j))}, {j << 6}, {vr(KVO(0))}" for j in range(1, NJK)]
     if prof:                         # s71..s75: cycles in M, at the barrier behind it, in V, in the DMA wait, at the barrier behind that
         out += ["s_memtime s[68:69]", "s_waitcnt lgkmcnt(0)", "s_mov_b32 s70, s68"] + [f"s_mov_b32 s{a}, 0" for a in range(71, 76)]
     if SYNC == "two":
@@ -514,8 +534,8 @@ def render():
              f"#define NNOP_DUO_SLOTS_PER_GROUP {SLOTS}      // ring slots per key group and ring (where the DMA batch is issued decides)\n"
              f"#define NNOP_DUO_VALU_SUMS {1 if SUMS == 'valu' else 0}            // 1: row sums by v_add_f32 in the vector phase (4 chains in v[248:251])\n"
              f"#define NNOP_DUO_SYNC_ONE {1 if SYNC == 'one' else 0}             // 1: one barrier per iteration, no barrier of group 1 in front of the statement\n"]
-    for nz in (2, 1):
-        set_nz(nz)
+    for nz, e in ((2, 64), (1, 64), (1, 128)):
+        set_nz(nz, e)
         for masked in (False, True):
             check_stream(loop(masked))
     set_nz(2)
@@ -525,6 +545,12 @@ def render():
     parts.append("// the same loop with ONE 32-row query block per wave (128-row workgroups): the z = 1 registers and instructions left out\n")
     parts.append(as_macro("NNOP_DUO1_LOOP_PLAIN", loop(False)))
     parts.append(as_macro("NNOP_DUO1_LOOP_MASKED", loop(True)))
+    set_nz(1, 128)
+    parts.append("// E = 128, one 32-row query block per wave: 16 + 16 MFMAs per tile, 2 ring slots per key group, the DMA batch in the vector phase,\n"
+                 "// a barrier behind every phase (group 1 enters behind a barrier of its own in front of the statement)\n"
+                 f"#define NNOP_DUO128_SLOTS_PER_GROUP {SLOTS}\n#define NNOP_DUO128_SYNC_ONE {1 if SYNC == 'one' else 0}\n")
+    parts.append(as_macro("NNOP_DUO128_LOOP_PLAIN", loop(False)))
+    parts.append(as_macro("NNOP_DUO128_LOOP_MASKED", loop(True)))
     set_nz(2)
     parts.append("// profile builds (make DEV=1 VAR=-DNNOP_DUO_STAMP=1): the same loops with s_memtime ticks; the five accumulators leave in v[224:228]\n"
                  "#ifdef NNOP_DEV_BUILD")
