@@ -112,17 +112,14 @@ static inline bool bwd_w64_ok(const nnop_fa_desc& d, int kind) {
     return (long long)d.kl * rb < (1LL << 32) && d.kl <= 64 * kMaxMaskTiles;
 }
 // The narrow shape of that form (BwdW64Shape NARROW: 32 stationary rows per wave, 128-row workgroups) where the 256-row blocks of a pass
-// leave CUs idle -- the forward's rule (fa_fwd_inst.hpp fwd_duo_nz).  Knob kTuneBwdNarrow: 0 never, 1 wherever instantiated.
+// leave CUs idle -- the forward's rule (small_grid_prefers_32_row_waves, fa_launch.hpp), per pass: the dK/dV pass counts kv heads.
+// Knob kTuneBwdNarrow: 0 never, 1 wherever instantiated.
 static inline bool bwd_w64_narrow(const nnop_fa_desc& d, int kind) {
     if (d.emb != 64 && d.emb != 128) return false;
     const int knob = tune_get(kTuneBwdNarrow);
     if (knob >= 0) return knob != 0;
     const int len = kind == kBwdDQ ? d.ql : d.kl, hd = kind == kBwdDQ ? d.qh : d.kh;
-    const long long w2 = (long long)((len + 255) / 256) * hd * d.batch, w1 = (long long)((len + 127) / 128) * hd * d.batch;
-    const long long cus = device_cu_count() > 0 ? device_cu_count() : 256;
-    if (d.causal) return 2 * w2 <= 3 * cus;
-    const long long r2 = (w2 + cus - 1) / cus, r1 = (w1 + cus - 1) / cus;
-    return 62 * r1 < 100 * r2;
+    return small_grid_prefers_32_row_waves(len, (long long)hd * d.batch, d.causal != 0);
 }
 // bit 0: dK/dV runs fa_bwd_w64_kernel, bit 1: dQ does (knob kTuneBwdW64: 0 never, 1 both, 2 dK/dV only, 3 dQ only, 4 both with the
 // preprocess launch kept, auto = both)

@@ -180,23 +180,14 @@ static int launch_fwd_mode(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t 
 static inline int fwd_mode(const nnop_fa_desc& d, bool has_pair, bool has_mask) {
     return has_pair ? 2 : ((d.causal || has_mask || (d.kl % 64) != 0) ? 1 : 0);
 }
-// Rows per wave of the two-waves-per-SIMD form: 64 (NZ = 2, 256-row workgroups), or 32 (NZ = 1: twice the workgroups at ~0.62 of the time
-// each -- every fragment read feeds one MFMA instead of two) where the 256-row blocks leave CUs idle.  Measured (MI355X, 256 CUs,
-// tools/duo_check.py with DUO_MODES=0,2,3, profiles/r04/nz1_sweep.log): equal-work blocks (plain, key padding) -- 32-row waves 1.35-1.6x
-// faster while the 128-row blocks still fit one round (L1024 H8 B4: 19.8 -> 14.0 us; L2048 H4 B4: 30.9 -> 21.4 us), +7 % where they turn
-// 2 rounds into 3 (L2048 H16 B3), 10-20 % SLOWER from there on; causal -- the finer blocks also even out the triangle: faster up to a
-// round and a half of 256-row blocks (L4096 H8 B2: 57.6 -> 45.1 us; L8192 H8 B1: 104.6 -> 79.6 us; L2048 H16 B3, 384 blocks: 55.3 ->
-// 47.3 us), 12 % slower from two rounds on.
-// Knob kTuneFwdDuo: 2 / 3 force NZ = 2 / 1.
+// Rows per wave of the two-waves-per-SIMD form at E = 64: 64 (NZ = 2, 256-row workgroups), or 32 (NZ = 1: twice the workgroups) where the
+// 256-row blocks leave CUs idle (small_grid_prefers_32_row_waves, fa_launch.hpp; L1024 H8 B4: 19.8 -> 14.0 us; L2048 H4 B4: 30.9 -> 21.4 us;
+// causal L4096 H8 B2: 57.6 -> 45.1 us; L8192 H8 B1: 104.6 -> 79.6 us).  Knob kTuneFwdDuo: 2 / 3 force NZ = 2 / 1.
 static inline int fwd_duo_nz(const nnop_fa_desc& d) {
     const int duo = tune_get(kTuneFwdDuo);
     if (duo == 2) return 2;
     if (duo == 3) return 1;
-    const long long w2 = (long long)((d.ql + 255) / 256) * d.qh * d.batch, w1 = (long long)((d.ql + 127) / 128) * d.qh * d.batch;
-    const long long cus = device_cu_count() > 0 ? device_cu_count() : 256;
-    if (d.causal) return 2 * w2 <= 3 * cus ? 1 : 2;
-    const long long r2 = (w2 + cus - 1) / cus, r1 = (w1 + cus - 1) / cus;
-    return 62 * r1 < 100 * r2 ? 1 : 2;
+    return small_grid_prefers_32_row_waves(d.ql, (long long)d.qh * d.batch, d.causal != 0) ? 1 : 2;
 }
 static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
     const bool b16 = d.dtype != NNOP_F32;

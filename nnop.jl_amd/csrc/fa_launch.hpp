@@ -101,6 +101,19 @@ inline int device_cu_count() {
     return v;
 }
 
+// Do 128-row workgroups of 32-row waves beat 256-row workgroups of 64-row waves for `len` stationary rows x `cols` (batch x head)
+// columns?  The 32-row forms (fa_fwd_duo.hpp NZ = 1, BwdW64Shape NARROW) do ~0.62 of a 256-row block's work time per 128-row block
+// (one MFMA per fragment read), so they pay where they turn idle CUs into busy ones.  Measured on 256 CUs (profiles/r04/nz1_sweep.log,
+// bwd_narrow.log): equal-work blocks -- 1.35-1.6x faster while the 128-row blocks fit one round, +7 % where they make 3 rounds of 2,
+// slower from there on; causal -- the finer blocks also even out the triangle: ahead up to a round and a half of 256-row blocks.
+inline bool small_grid_prefers_32_row_waves(int len, long long cols, bool causal) {
+    const long long w2 = (long long)((len + 255) / 256) * cols, w1 = (long long)((len + 127) / 128) * cols;
+    const long long cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    if (causal) return 2 * w2 <= 3 * cus;
+    const long long r2 = (w2 + cus - 1) / cus, r1 = (w1 + cus - 1) / cus;
+    return 62 * r1 < 100 * r2;
+}
+
 // Kernels that need more than 64 KiB of dynamic LDS must opt in once per (kernel, device).  `done` is a per-kernel
 // static bitmap (one bit per device ordinal < 64); setting the attribute twice is harmless, so a benign race between
 // host threads only costs a redundant call.
