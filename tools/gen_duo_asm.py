@@ -118,6 +118,12 @@ def set_nz(nz, e=64):
     TILE_SHIFT, ROWB = (13, 128) if e == 64 else (14, 256)
     DMA_AT, SLOTS, SYNC = (_DMA64, _SLOTS64, _SYNC64) if e == 64 else ("v", 2, "two")
 
+# the scale-and-shift of the logits (s c2 - m2) as v_pk_fma_f32 over register pairs (one instruction per two logits; the scale in the scalar
+# pair s[66:67], -m2 broadcast from one register of v[208:209] by op_sel) instead of one v_fma_f32 per logit.  Measured
+# (profiles/r04/duo_pkfma.log): 10 % SLOWER (C2 67.5 -> 74.4 us) -- the packed form holds the vector port longer than the two
+# instructions it replaces; results identical.  Off.
+PKFMA = int(os.environ.get("NNOP_DUO_GEN_PKFMA", "0"))
+
 # timing-only ablations (results WRONG by construction; never committed): NNOP_DUO_GEN_ABL bit mask
 #   1 no LDS-DMA in the loop   2 no row-max fillers   4 no exp / fma / convert in the vector phase   8 no MFMAs and no fragment reads
 ABL = int(os.environ.get("NNOP_DUO_GEN_ABL", "0"))
@@ -303,7 +309,12 @@ def v_softmax(l1=4, l2=4, dma_at=()):
     for step in range(NEL + l1 + l2):
         if step in dma_at:
             out += dma_piece(pieces.pop(0))
-        if step < NEL:
+        if step < NEL and PKFMA:
+            r, z, _, _ = reg(step)
+            if step % 2 == 0:
+                sel = "op_sel_hi:[1,0,0]" if z == 0 else "op_sel:[0,0,1] op_sel_hi:[1,0,1]"
+                out.append(f"v_pk_fma_f32 {vr(r, 2)}, {vr(r, 2)}, s[66:67], {vr(NM(0), 2)} {sel}")
+        elif step < NEL:
             r, z, _, _ = reg(step)
             out.append(f"v_fma_f32 {vr(r)}, {vr(r)}, {sr(SC2)}, {vr(NM(z))}")
         e = step - l1
@@ -424,6 +435,8 @@ def loop(masked, prof=False):
     PV(t) happens in M(t + 2)."""
     out = []
     out += [f"v_mov_b32 {vr(NM(z))}, 0" for z in range(NZ)] + [f"v_mov_b32 {vr(THR(z))}, 0xff800000" for z in range(NZ)]     # m2 = -inf
+    if PKFMA:
+        out += [f"v_readfirstlane_b32 s66, {sr(SC2)}", f"v_readfirstlane_b32 s67, {sr(SC2)}"]        # (the scale operand arrives in a VGPR)
     if E == 128:
         # DMA source offsets of this wave's K pieces 1..3: piece j covers image rows 4 j .. 4 j + 3 of the wave's 16 and the image XORs a
         # row's 16-byte chunks with row & 15, so offset j = offset 0 with chunk bits 2..3 flipped by j
