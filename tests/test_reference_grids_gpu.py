@@ -89,8 +89,10 @@ def _run(pkg, dev, dt, c, causal):
 # problem without a pair bias is the one-wave-per-SIMD form (csrc/fa_bwd_w64.hpp) by default.  `form = "w64"` runs a grid point once
 # more with the 64-row forward FORCED (16-bit types, E = 64 -- and an E = 128 slice the reference does not have, in the causal and
 # GQA grids --, no pair bias: that mode stays on the 32-row kernel); the two 16-bit types alternate over the points (suite time).
-# Round 4: `form = "duo"` does the same for the two-waves-per-SIMD forward (csrc/fa_fwd_duo.hpp: 16-bit, E = 64, no pair bias) -- the
-# kernel bench.py times at C2; the launcher picks it from KL = 1024 up only.  It takes the OTHER 16-bit type of each point.
+# Round 4: `form = "duo"` does the same for the two-waves-per-SIMD forward (csrc/fa_fwd_duo.hpp: 16-bit, E = 64, no pair bias) with its
+# 64-ROW waves (knob 2) -- the kernel bench.py times at C2, which the launcher picks from KL = 1024 up on grids that fill the chip.  It
+# takes the OTHER 16-bit type of each point.  (These small grids reach the 32-row-wave loops of that form, E = 64 and E = 128, and the
+# narrow backward shape by themselves: `form = "auto"` from KL = 256.)
 FORMS = ["auto", "w64", "duo"]
 
 
@@ -118,7 +120,7 @@ def test_flash_attention_grid(pkg, dev, tune, dt, form, KL, QL, E, use_pair, use
     if form == "duo":
         if not _duo_applies(dt, E, use_pair, QL + KL + use_padmask):
             pytest.skip("two-waves-per-SIMD forward: 16-bit, E = 64, no pair bias; the two types alternate")
-        tune(fwd_duo=1, bwd_w64=1)
+        tune(fwd_duo=2, bwd_w64=1)
     if dt == "f16" and (E < 64 or (use_pair and QL != KL)) and form == "auto":
         # suite time (round-2 verdict: drop dtype repeats where the kernel form is identical): fp16 and bf16 run the same kernel
         # templates and differ in the MFMA opcode only; fp16 stays on the E = 64 slice without a bias here, on the QL = KL slice
@@ -144,7 +146,7 @@ def test_causal_flash_attention_grid(pkg, dev, tune, dt, form, L, E, use_pair, u
     elif form == "duo":
         if dt == "f32" or E != 64 or use_pair:
             pytest.skip("two-waves-per-SIMD forward: 16-bit, E = 64, no pair bias")
-        tune(fwd_duo=1, bwd_w64=1)
+        tune(fwd_duo=2, bwd_w64=1)
     elif E == 128:
         pytest.skip("E = 128 is not in the reference's grid: the added slice runs on the 64-row kernels only")
     H, B = 2, 3
@@ -168,7 +170,7 @@ def test_grouped_query_attention_grid(pkg, dev, tune, dt, form, L, E, causal, KV
     elif form == "duo":
         if not _duo_applies(dt, E, False, L + QH + KVH + causal):
             pytest.skip("two-waves-per-SIMD forward: 16-bit, E = 64; the two types alternate")
-        tune(fwd_duo=1, bwd_w64=1)
+        tune(fwd_duo=2, bwd_w64=1)
     elif E == 128:
         pytest.skip("E = 128 is not in the reference's grid: the added slice runs on the 64-row kernels only")
     B = 2
