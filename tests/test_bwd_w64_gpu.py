@@ -17,6 +17,11 @@ def shape(request, tune):
     """both wave shapes of the kernel template on every case of this file: 64 stationary rows per wave (256-row workgroups) and the
     narrow one (BwdW64Shape NARROW: 32 rows per wave, 64 streamed rows per step, 128-row workgroups) that the launcher picks where
     256-row blocks would leave CUs idle (knob bwd_narrow; tests below for the rule itself)"""
+    # suite time: fp16 and bf16 run the same kernel templates (they differ in the MFMA opcode); the narrow shape runs its fp16 repeats
+    # only where a test has no bf16 twin
+    dt = request.node.callspec.params.get("dt") if hasattr(request.node, "callspec") else None
+    if request.param == 1 and dt == "f16" and "test_noncausal" not in request.node.name:
+        pytest.skip("narrow shape: fp16 repeat of a bf16 case")
     tune(bwd_narrow=request.param)
     return request.param
 

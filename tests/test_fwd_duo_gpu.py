@@ -27,6 +27,11 @@ def duo(request):
     (128-row workgroups, the loop without its z = 1 half, the partners splitting the epilogue by columns); 1 = on, the launcher picks
     the rows per wave from the grid.  E = 128: 32-row waves only (16 KiB tiles: 2 ring slots per key group, the LDS-DMA batch in the
     vector phase, a barrier behind every phase)"""
+    # suite time: fp16 and bf16 run the same generated loop (the type is one mnemonic suffix); the 32-row loops keep their fp16 repeats
+    # in the plain / causal sweeps and the reproducibility test only
+    dt = request.node.callspec.params.get("dt") if hasattr(request.node, "callspec") else None
+    if request.param != (2, 64) and dt == "f16" and not any(k in request.node.name for k in ("test_plain", "test_causal", "test_bitwise")):
+        pytest.skip("32-row loops: fp16 repeat of a bf16 case")
     return Shape(*request.param)
 
 
