@@ -179,3 +179,18 @@ def test_shard_entry_equals_the_python_sharding(pkg, B, KH, rep):
                 seen += [(b, h) for b in range(s.b0, s.b1) for h in range(s.kh0, s.kh1)]
         assert sorted(seen) == [(b, h) for b in range(B) for h in range(KH)]
     assert pkg._lib.load().nnop_fa_shards(C.byref(d), 2, 2, (pkg._lib.FaShard * 3)()) == pkg._lib.NNOP_ERR_SHAPE
+
+
+def test_launcher_form_rules_without_a_device(pkg):
+    """the launcher's choice of forward kernel is a plain function of the descriptor (csrc/fa_fwd_inst.hpp fwd_form_of; with no device the
+    rules assume 256 CUs): the two-waves-per-SIMD form from KL = 1024 on grids that fill the chip, its 32-row-wave loops (E = 64 and
+    E = 128) on launches that would leave CUs idle with 256-row blocks, the one-wave form at E = 128 otherwise"""
+    mk = lambda **kw: pkg._lib.FaDesc(**dict(dict(dtype=2, emb=64, ql=4096, kl=4096, qh=4, kh=4, batch=4, causal=0, emb_k=0, emb_v=0, kl_v=0, kh_v=0), **kw))
+    f = pkg._lib.fwd_form
+    assert f(mk()) == "fa_fwd_duo_kernel"                                                  # C2
+    assert f(mk(emb=128, ql=8192, kl=8192, qh=32, kh=32, batch=8, causal=1)) == "fa_fwd_w64_kernel"      # C3
+    assert f(mk(ql=512, kl=512)) == "fa_fwd_duo_kernel" and f(mk(ql=512, kl=512, batch=64)) != "fa_fwd_duo_kernel"
+    assert f(mk(emb=128, ql=2048, kl=2048, causal=1)) == "fa_fwd_duo_kernel"               # 256 blocks of 128 rows: one round
+    assert f(mk(emb=128, ql=2048, kl=2048, batch=16)) == "fa_fwd_w64_kernel"
+    assert f(mk(dtype=0)) not in ("fa_fwd_duo_kernel", "fa_fwd_w64_kernel")                # fp32: the 32-row tiled kernels
+    assert f(mk(), True, False) != "fa_fwd_duo_kernel"                                     # pair bias: 32-row kernel
