@@ -4,6 +4,8 @@ pass has not landed.  tools/audit_w64.py models the instruction stream (control 
 scratch and stray M0 uses; this test runs it on the shipped sources -- and on a build with the source-level fences compiled
 out, which it must flag (that is the bug the fences fix: stale accumulator registers 13..15 of one O tile at E = 64)."""
 import os
+
+import pytest
 import subprocess
 import sys
 
@@ -15,6 +17,15 @@ def test_shipped_w64_kernels_pass_the_audit():
     r = subprocess.run([sys.executable, AUDIT, "--only", "fwd"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(": OK") == 20         # {bf16, f16} x ({E64, E128} x {plain, masked} x {scale folded into Q, exact} + E256 x {plain, masked})
+
+
+@pytest.fixture(scope="module", autouse=True)
+def compiled_once():
+    """the five device-assembly compiles this file's tests look at (a minute each), side by side, into the cache of tools/audit_w64.py"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from audit_w64 import prewarm
+    prewarm([("fa_fwd_bf16.hip", []), ("fa_fwd_f16.hip", []), ("fa_bwd_bf16.hip", []), ("fa_bwd_f16.hip", []),
+             ("fa_fwd_bf16.hip", ["-DNNOP_W64_NO_LEAVE_FENCE=1"]), ("fa_fwd_f16.hip", ["-DNNOP_W64_NO_LEAVE_FENCE=1"])])
 
 
 def test_shipped_backward_w64_kernels_pass_the_audit():

@@ -49,6 +49,13 @@ def compile_asm(src, extra):
     return text
 
 
+def prewarm(jobs):
+    """compile several (src, extra flags) pairs at once into the cache (the compiles are independent minutes of single-threaded hipcc)"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        list(ex.map(lambda j: compile_asm(*j), jobs))
+
+
 def kernels(text, pattern):
     for m in re.finditer(r"^(_ZN4nnop\w*" + pattern + r"\w*):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
         meta = re.search(r"\.name:\s+" + re.escape(m.group(1)) + r"\n(.*?)\.wavefront_size", text, re.S)
