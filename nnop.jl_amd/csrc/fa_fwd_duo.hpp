@@ -1,4 +1,5 @@
-// fa_fwd_duo.hpp -- forward kernel, "two waves per SIMD in alternating phases" form (16-bit types, E = 64).
+// fa_fwd_duo.hpp -- forward kernel, "two waves per SIMD in alternating phases" form (16-bit types; E = 64 with 64- or 32-row waves,
+// E = 128 with 32-row waves).  The text below describes the E = 64, 64-row form; the variants are at its end.
 //
 // What `_flash_attention_fwd!` computes (src/attention.jl:1-131; its hot loop :49-121), fourth program form.  Why it exists: at
 // E = 64 one 32x32x16 MFMA covers only two score elements per lane, and each element costs one v_exp_f32 (8 cycles of the SIMD's
@@ -31,6 +32,15 @@
 //   * K / V rings of 6 slots per tensor, 3 per key group (read now / landed or landing / free), filled by LDS-DMA (the group that
 //     reads a tile also copies it): the batch K(t+4), V(t+2) issued at the tail of M(t) goes to the group's free slots (what they
 //     held was read two barriers back), is waited for one iteration later (vmcnt(4)) and read in M(t+4) / M(t+4).
+//
+//   * variants (template parameter NZ = 32-row query blocks per wave; the generator's set_nz):
+//     NZ = 1, E = 64   the same loop without its z = 1 half: 32 rows per wave, 128 per workgroup -- for launches whose 256-row blocks
+//                      would leave CUs idle (fa_launch.hpp small_grid_prefers_32_row_waves).  The partners finish the same 32 rows, group 0
+//                      the first half of the columns and the residuals, group 1 the second.
+//     NZ = 1, E = 128  O^T is again 64 registers (32 rows x 128 columns), Q eight fragments; tiles of 16 KiB -> 2 ring slots per key group,
+//                      the LDS-DMA batch (8 pieces per wave) in the VECTOR phase behind the barrier that closes the matrix phase whose
+//                      slots it overwrites, a barrier behind every phase.  LDS-bound per tile (slower than fa_fwd_w64.hpp on grids that
+//                      fill the chip), launched on small grids only (fa_fwd_inst.hpp fwd_form_of).
 //
 // Modes: 0 plain / 1 masked (causal, key padding, ragged KL).  Exact fp32 scale only.  Same numerics contract as the other forms
 // (fp32 softmax, deferred row max with threshold 2^8, O normalised once, residuals ms / ls per src/attention.jl:128-129); the
