@@ -138,16 +138,26 @@ __global__ __launch_bounds__(256) void fa_bwd_pre_kernel(const BwdParams p, long
     }
 }
 
-// store a transposed accumulator (rows = embedding in registers, column = this lane's sequence row)
-template <typename T, int E>
-NNOP_DEV void store_acc_row(T* rowp, const f32x16* acc, float mul, int h) {
-    constexpr int EB = (E + 31) / 32;
+// fp32 E = 256: the gradient accumulators of a 32-row wave (dK^T + dV^T: 256 registers, dQ^T: 128) do not fit beside the fragments and
+// tiles -- every block runs as fa_bwd_split() workgroups that each recompute the score tiles (full E) and accumulate ONE slice of the
+// columns (blockIdx.x / n_wg picks it), as the 16-bit E = 256 one-wave kernels do (fa_bwd_w64.hpp NSPLIT).  Two slices: 6 product-units
+// for 4 (dK/dV), 5 for 3 (dQ), and twice the workgroups for the one-round launches this embedding dim mostly sees.
+#ifndef NNOP_F32_E256_SPLIT
+#define NNOP_F32_E256_SPLIT 2
+#endif
+template <typename T, int E> constexpr int fa_bwd_split() { return (sizeof(T) == 4 && E == 256) ? NNOP_F32_E256_SPLIT : 1; }
+
+// store a transposed accumulator (rows = embedding in registers, column = this lane's sequence row); EBA column blocks from block eb0 on
+template <typename T, int E, int EBA = (E + 31) / 32>
+NNOP_DEV void store_acc_row(T* rowp, const f32x16* acc, float mul, int h, int eb0 = 0) {
+    constexpr int EB = EBA;
+    rowp += 32 * eb0;
 #pragma unroll
     for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int e = 32 * eb + 8 * g + 4 * h;
-            if (e < E) {
+            if (e < E) {                                   // (E < 32: the padded columns; a slice never reaches past E)
                 f32x4 w = {acc[eb][4 * g] * mul, acc[eb][4 * g + 1] * mul, acc[eb][4 * g + 2] * mul,
                            acc[eb][4 * g + 3] * mul};
                 if constexpr (sizeof(T) == 4) {
@@ -182,7 +192,8 @@ template <typename T, int E> struct BwdImgs {
 // registers during the compute phase and written after a barrier -- which frees the LDS for 7-wave workgroups
 // (224 keys: 112 KiB of K, V images + 32 KiB of tile), i.e. ~2 waves per SIMD instead of 1.
 // (chosen by the launcher: NW == 7 <=> single-buffered)
-template <typename T, int E, int NW> constexpr bool fa_bwd_single() { return sizeof(T) == 2 && ((E > 64 && NW == 7) || E > 128); }
+// (fp32 E = 256: 1 KiB rows -- one wave's K, V images (64 KiB) + one Q, dO tile (64 KiB) is what 160 KiB hold)
+template <typename T, int E, int NW> constexpr bool fa_bwd_single() { return (sizeof(T) == 2 && ((E > 64 && NW == 7) || E > 128)) || (sizeof(T) == 4 && E > 128); }
 
 // dK/dV kernel: which of the workgroup's K / V fragments live in registers for the whole kernel (else: LDS row images)
 // fp32 E = 128 (one wave per SIMD, 512 registers): K and V fragments (64 registers each) beside the 128 accumulator registers --
@@ -192,10 +203,22 @@ template <typename T, int E, int NW> constexpr bool fa_bwd_single() { return siz
 #define NNOP_F32_E128_REGS 1
 #endif
 template <typename T, int E> constexpr bool fa_bwd_f32_wide() { return NNOP_F32_E128_REGS && sizeof(T) == 4 && E == 128; }
-template <typename T, int E, int MODE> constexpr bool fa_bwd_dkdv_vregs() { return E <= 64 || (NNOP_F32_E128_REGS == 2 && fa_bwd_f32_wide<T, E>()); }
+// fp32 E = 256 (round 4; the plain-HIP kernels of fa_generic.hpp before: 1.3 TFLOP/s): the same form one size up -- K AND V fragments
+// (dK/dV) / Q and dO fragments (dQ) in registers (2 x 128), so that LDS holds only the streamed tiles and a 4-wave workgroup fits, with
+// the gradient accumulators column-split over fa_bwd_split() workgroups per block (below).  hipcc still spills ~90-130 registers there;
+// measured 20-24 TFLOP/s at L2048-4096 H8 B2 (profiles/r04/f32_e256_bwd.log: 1 wave with everything in LDS 7.5, K in registers and 2 waves
+// 8.3, this form 24.0 / 14.5 causal unsplit, 22.4 / 20.5 split in two).  NNOP_F32_E256_FORM: 0 / 1 / 2 = those three (A/B builds).
+#ifndef NNOP_F32_E256_FORM
+#define NNOP_F32_E256_FORM 2
+#endif
+template <typename T, int E> constexpr bool fa_bwd_f32_e256() { return sizeof(T) == 4 && E == 256; }
+template <typename T, int E, int MODE> constexpr bool fa_bwd_dkdv_vregs() {
+    return E <= 64 || (NNOP_F32_E128_REGS == 2 && fa_bwd_f32_wide<T, E>()) || (NNOP_F32_E256_FORM == 2 && fa_bwd_f32_e256<T, E>());
+}
 template <typename T, int E, int MODE, int NW = 8> constexpr bool fa_bwd_dkdv_kregs() {
     // E = 128: only the 8-wave form (the 4-wave masked kernel spills 25 registers with K on top and measured 2 % slower)
-    return E <= 64 || (NNOP_DKDV_KREGS128 && sizeof(T) == 2 && E == 128 && MODE <= 1 && NW == 8) || fa_bwd_f32_wide<T, E>();
+    return E <= 64 || (NNOP_DKDV_KREGS128 && sizeof(T) == 2 && E == 128 && MODE <= 1 && NW == 8) || fa_bwd_f32_wide<T, E>() ||
+           (NNOP_F32_E256_FORM >= 1 && fa_bwd_f32_e256<T, E>());
 }
 // with K out of LDS the streamed tiles fit twice even at 7 / 8 waves
 template <typename T, int E, int NW, int MODE> constexpr bool fa_bwd_dkdv_single() {
@@ -233,8 +256,11 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    const int lin  = (kPair && !kStaged) ? xcd_remap_heads((int)blockIdx.x, p.n_blk, p.KH, p.n_wg / p.KH)
-                                         : xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk);      // chunk = one (batch, kv-head)
+    constexpr int NSPLIT = fa_bwd_split<T, E>(), EBA = EB / NSPLIT;
+    const int bid = NSPLIT > 1 ? (int)blockIdx.x % p.n_wg : (int)blockIdx.x;
+    const int eb0 = NSPLIT > 1 ? ((int)blockIdx.x / p.n_wg) * EBA : 0;      // first column block this workgroup accumulates
+    const int lin  = (kPair && !kStaged) ? xcd_remap_heads(bid, p.n_blk, p.KH, p.n_wg / p.KH)
+                                         : xcd_remap_chunked(bid, p.n_wg, p.n_blk);      // chunk = one (batch, kv-head)
     const int kblk = lin % p.n_blk;
     const int bk   = lin / p.n_blk;
     const int b    = bk / p.KH;
@@ -255,14 +281,14 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         // variable sequence length: a key block with no valid key gets dK = dV = 0 and does no work
         if (p.kpad && !__syncthreads_or(kvalid ? 1 : 0)) {
             if (key < p.KL) {
-                f32x16 zero[EB];
+                f32x16 zero[EBA];
 #pragma unroll
-                for (int eb = 0; eb < EB; ++eb)
+                for (int eb = 0; eb < EBA; ++eb)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) zero[eb][i] = 0.f;
                 const size_t ro = ((size_t)(b * p.KH + kvh) * p.KL + key) * E;
-                store_acc_row<T, E>((T*)p.dk + ro, zero, 0.f, h);
-                store_acc_row<T, E>((T*)p.dv + ro, zero, 0.f, h);
+                store_acc_row<T, E, EBA>((T*)p.dk + ro, zero, 0.f, h, eb0);
+                store_acc_row<T, E, EBA>((T*)p.dv + ro, zero, 0.f, h, eb0);
             }
             return;
         }
@@ -330,9 +356,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         }
     };
 
-    f32x16 dka[EB], dva[EB];
+    f32x16 dka[EBA], dva[EBA];
 #pragma unroll
-    for (int eb = 0; eb < EB; ++eb)
+    for (int eb = 0; eb < EBA; ++eb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dka[eb][i] = 0.f; dva[eb][i] = 0.f; }
 
@@ -442,18 +468,18 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
             const frag_t p0 = acc_frag<T, 0>(s), p1 = acc_frag<T, 1>(s);
             const frag_t d0 = acc_frag<T, 0>(ds), d1 = acc_frag<T, 1>(ds);
 #pragma unroll
-            for (int eb = 0; eb < EB; ++eb) {
+            for (int eb = 0; eb < EBA; ++eb) {
                 frag_t a0, a1, b0, b1;
                 if constexpr (Imgs::kDual) {
-                    a0 = Row::read_col_frag_f32(dorow, r, h, 2 * qb, eb);
-                    a1 = Row::read_col_frag_f32(dorow, r, h, 2 * qb + 1, eb);
-                    b0 = Row::read_col_frag_f32(qrow, r, h, 2 * qb, eb);
-                    b1 = Row::read_col_frag_f32(qrow, r, h, 2 * qb + 1, eb);
+                    a0 = Row::read_col_frag_f32(dorow, r, h, 2 * qb, eb0 + eb);
+                    a1 = Row::read_col_frag_f32(dorow, r, h, 2 * qb + 1, eb0 + eb);
+                    b0 = Row::read_col_frag_f32(qrow, r, h, 2 * qb, eb0 + eb);
+                    b1 = Row::read_col_frag_f32(qrow, r, h, 2 * qb + 1, eb0 + eb);
                 } else {
-                    a0 = Col::read_col_frag(docol, 2 * qb, eb);
-                    a1 = Col::read_col_frag(docol, 2 * qb + 1, eb);
-                    b0 = Col::read_col_frag(qcol, 2 * qb, eb);
-                    b1 = Col::read_col_frag(qcol, 2 * qb + 1, eb);
+                    a0 = Col::read_col_frag(docol, 2 * qb, eb0 + eb);
+                    a1 = Col::read_col_frag(docol, 2 * qb + 1, eb0 + eb);
+                    b0 = Col::read_col_frag(qcol, 2 * qb, eb0 + eb);
+                    b1 = Col::read_col_frag(qcol, 2 * qb + 1, eb0 + eb);
                 }
                 dva[eb] = mma16<T>(a0, p0, dva[eb]);
                 dva[eb] = mma16<T>(a1, p1, dva[eb]);
@@ -471,14 +497,14 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         if constexpr (kGeneral) {
             if (!kvalid) {                                  // padded-out key: its lane accumulated garbage (see above)
 #pragma unroll
-                for (int eb = 0; eb < EB; ++eb)
+                for (int eb = 0; eb < EBA; ++eb)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { dka[eb][i] = 0.f; dva[eb][i] = 0.f; }
             }
         }
         const size_t ro = ((size_t)(b * p.KH + kvh) * p.KL + key) * E;
-        store_acc_row<T, E>((T*)p.dk + ro, dka, p.scale, h);
-        store_acc_row<T, E>((T*)p.dv + ro, dva, 1.0f, h);
+        store_acc_row<T, E, EBA>((T*)p.dk + ro, dka, p.scale, h, eb0);
+        store_acc_row<T, E, EBA>((T*)p.dv + ro, dva, 1.0f, h, eb0);
     }
 }
 
@@ -494,7 +520,7 @@ constexpr int kMaxMaskTilesBwd = 1024;       // key padding: one 64-bit validity
 // images every tile)?  16-bit: E <= 64 always; E = 128 in the plain / masked modes (252-256 registers, no spills; the
 // pair-bias modes would spill ~50) -- which also frees 112 KiB of LDS: those kernels are double-buffered and run 8 waves.
 template <typename T, int E, int MODE> constexpr bool fa_bwd_dq_qregs() {
-    return sizeof(T) == 2 ? (E <= 64 || (E == 128 && MODE <= 1)) : (E <= 32 || fa_bwd_f32_wide<T, E>());
+    return sizeof(T) == 2 ? (E <= 64 || (E == 128 && MODE <= 1)) : (E <= 32 || fa_bwd_f32_wide<T, E>() || (NNOP_F32_E256_FORM == 2 && fa_bwd_f32_e256<T, E>()));
 }
 template <typename T, int E, int NW, int BK, int MODE>
 constexpr int fa_bwd_dq_lds_bytes() {
@@ -528,8 +554,11 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    int lin = (kPair && !kStaged) ? xcd_remap_heads((int)blockIdx.x, p.n_blk, p.QH, p.n_wg / p.QH)
-                                  : xcd_remap_chunked((int)blockIdx.x, p.n_wg, p.n_blk * (p.QH / p.KH));
+    constexpr int NSPLIT = fa_bwd_split<T, E>(), EBA = EB / NSPLIT;
+    const int bid = NSPLIT > 1 ? (int)blockIdx.x % p.n_wg : (int)blockIdx.x;
+    const int eb0 = NSPLIT > 1 ? ((int)blockIdx.x / p.n_wg) * EBA : 0;      // first column block this workgroup accumulates
+    int lin = (kPair && !kStaged) ? xcd_remap_heads(bid, p.n_blk, p.QH, p.n_wg / p.QH)
+                                  : xcd_remap_chunked(bid, p.n_wg, p.n_blk * (p.QH / p.KH));
     int qblk = lin % p.n_blk;
     const int bh = lin / p.n_blk;
     if (p.causal) qblk = p.n_blk - 1 - qblk;
@@ -602,9 +631,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         sv.template write<Row>(buf + KIMG, tid);
     };
 
-    f32x16 dqa[EB];
+    f32x16 dqa[EBA];
 #pragma unroll
-    for (int eb = 0; eb < EB; ++eb)
+    for (int eb = 0; eb < EBA; ++eb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dqa[eb][i] = 0.f;
     const int cbase = Col::lane_base(lane);
@@ -742,14 +771,14 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                 }
                 const frag_t d0 = acc_frag<T, 0>(ds), d1 = acc_frag<T, 1>(ds);
 #pragma unroll
-                for (int eb = 0; eb < EB; ++eb) {
+                for (int eb = 0; eb < EBA; ++eb) {
                     frag_t a0, a1;
                     if constexpr (Imgs::kDual) {
-                        a0 = Row::read_col_frag_f32(krow, r, h, 2 * kb, eb);
-                        a1 = Row::read_col_frag_f32(krow, r, h, 2 * kb + 1, eb);
+                        a0 = Row::read_col_frag_f32(krow, r, h, 2 * kb, eb0 + eb);
+                        a1 = Row::read_col_frag_f32(krow, r, h, 2 * kb + 1, eb0 + eb);
                     } else {
-                        a0 = Col::read_col_frag(kcol, 2 * kb, eb);
-                        a1 = Col::read_col_frag(kcol, 2 * kb + 1, eb);
+                        a0 = Col::read_col_frag(kcol, 2 * kb, eb0 + eb);
+                        a1 = Col::read_col_frag(kcol, 2 * kb + 1, eb0 + eb);
                     }
                     dqa[eb] = mma16<T>(a0, d0, dqa[eb]);
                     dqa[eb] = mma16<T>(a1, d1, dqa[eb]);
@@ -762,7 +791,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
         __syncthreads();
     }
 
-    if (qi < p.QL) store_acc_row<T, E>((T*)p.dq + ((size_t)bh * p.QL + qi) * E, dqa, p.scale, h);
+    if (qi < p.QL) store_acc_row<T, E, EBA>((T*)p.dq + ((size_t)bh * p.QL + qi) * E, dqa, p.scale, h, eb0);
 }
 
 }  // namespace nnop

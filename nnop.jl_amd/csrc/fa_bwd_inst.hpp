@@ -15,9 +15,10 @@ template <typename T, int E> struct BwdCfg {
     static constexpr bool kF32 = sizeof(T) == 4;
     // fp32 at E=128 keeps K,V (dkdv) / Q,dO (dq) in LDS instead of registers: fewer waves, smaller tiles
     // (16-bit E = 256: 2 waves, single-buffered tiles -- what fits 160 KiB of LDS)
-    static constexpr int NW_KV = ((kF32 && E > 64 && !fa_bwd_f32_wide<T, E>()) || E > 128) ? 2 : 4;
+    // (fp32 E = 256: 4 waves with the stationary fragments in registers, fa_bwd.hpp NNOP_F32_E256_FORM)
+    static constexpr int NW_KV = (kF32 && E > 128) ? (NNOP_F32_E256_FORM == 2 ? 4 : NNOP_F32_E256_FORM == 1 ? 2 : 1) : ((kF32 && E > 64 && !fa_bwd_f32_wide<T, E>()) || E > 128) ? 2 : 4;
     static constexpr int BQ    = (kF32 || E > 64) ? 32 : 64;
-    static constexpr int NW_Q  = ((kF32 && E > 64 && !fa_bwd_f32_wide<T, E>()) || E > 128) ? 2 : 4;
+    static constexpr int NW_Q  = (kF32 && E > 128) ? (NNOP_F32_E256_FORM == 2 ? 4 : 1) : ((kF32 && E > 64 && !fa_bwd_f32_wide<T, E>()) || E > 128) ? 2 : 4;
     // 16-bit E = 128, large grids: 7 waves (224 keys / queries per workgroup) with single-buffered tiles ->
     // ~2 waves per SIMD instead of 1 (LDS-limited); small grids keep 4 waves (finer quantization over 256 CUs)
     static constexpr bool kBig7 = !kF32 && E == 128;
@@ -39,7 +40,8 @@ static int launch_dkdv(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s)
     const long long n_wg = (long long)pk.n_blk * d.kh * d.batch;
     if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     pk.n_wg = (int)n_wg;
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, s, pk);
+    if (n_wg * fa_bwd_split<T, E>() > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg * fa_bwd_split<T, E>())), dim3(NW * 64), lds, s, pk);   // (fp32 E = 256: every block once per column slice)
     return NNOP_OK;
 }
 
@@ -55,7 +57,8 @@ static int launch_dq(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
     const long long n_wg = (long long)pq.n_blk * d.qh * d.batch;
     if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     pq.n_wg = (int)n_wg;
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(NW * 64), lds, s, pq);
+    if (n_wg * fa_bwd_split<T, E>() > 0x7fffffffLL) return NNOP_ERR_SHAPE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg * fa_bwd_split<T, E>())), dim3(NW * 64), lds, s, pq);
     return NNOP_OK;
 }
 
@@ -267,6 +270,10 @@ static int launch_bwd_cfg(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s
 
 template <typename T, int E>
 static int launch_bwd_e(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
+    if constexpr (sizeof(T) == 4 && E == 256) {
+        if (a.pair) return NNOP_ERR_EMB_UNSUPPORTED;             // (launch_bwd sends fp32 E = 256 with a pair bias to the plain-HIP kernels)
+        return (d.causal || a.kpad) ? launch_bwd_cfg<T, E, 1>(d, a, s) : launch_bwd_cfg<T, E, 0>(d, a, s);
+    } else
     if (a.pair) {
         // staged pair path when the caller brought the scratch for it (nnop_fa_bwd_workspace_bytes_pair)
         // (the scratch matrices are addressed with 16-byte vectors: a workspace that is not 16-byte aligned takes the direct path)
@@ -309,6 +316,8 @@ template <typename T> static int launch_bwd_generic(const nnop_fa_desc& d, const
 template <typename T> int launch_bwd(const nnop_fa_desc& d, const BwdArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         if (d.emb == 256) return launch_bwd_e<T, 256>(d, a, s);     // tiled kernels, 2 waves, single-buffered (see launch_fwd)
+    } else {
+        if (d.emb == 256 && !a.pair) return launch_bwd_e<T, 256>(d, a, s);     // fp32: tiled kernels, 1 wave (no pair-bias mode: plain HIP)
     }
     if (emb_generic(d.emb)) return launch_bwd_generic<T>(d, a, s);
     switch (d.emb) {
