@@ -99,6 +99,19 @@ namespace nnop {
           "v221", "v222", "v223", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70",    \
           "s71", "s72", "s73", "s74", "s75", "s76", "s77"
 
+// E = 32 (NZ = 2): one column block of O^T per query block (v[0:15], v[32:47]), two Q fragments each (v[64:71], v[80:87]); the rest as E = 64
+#define NNOP_DUO32_OPERANDS                                                                                                      \
+    "+{v[0:15]}"(oacc[0][0]), "+{v[32:47]}"(oacc[NZ - 1][0]), "+{v[64:79]}"(qf[0]), "+{v[80:95]}"(qf[NQT - 1]), "+{v[96:99]}"(lacc[0]),  \
+        "+{v[100:103]}"(lacc[NZ - 1]), "+{v[104:107]}"(sel), "+{v[112:127]}"(sc[0][0]), "+{v[128:143]}"(sc[0][1]),                       \
+        "+{v[144:159]}"(sc[NZ - 1][0]), "+{v[160:175]}"(sc[NZ - 1][1]), "+{v[192:195]}"(mstate), [st] "+s"(s_t), [ska] "+s"(s_ka),        \
+        [skb] "+s"(s_kb), [skc] "+s"(s_kc), [sva] "+s"(s_va), [svb] "+s"(s_vb), [svc] "+s"(s_vc)                                        \
+        : "{v[196:203]}"(vconst), [sh] "s"(s_h), [snlive] "s"(s_nlive), [slast] "s"(s_last), [sc2] "s"(c2), [scq0] "s"(s_cq0),            \
+          [svbits] "s"(s_vbits), [krs] "s"(krs), [vrs] "s"(vrs)                                                                       \
+        : "memory", "vcc", "scc", "v108", "v109", "v110", "v111", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", \
+          "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212",   \
+          "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "s56", "s57", "s58", "s59", "s60", "s61",  \
+          "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77"
+
 // E = 128 (NZ = 1): O^T = 4 column blocks, Q = 8 fragments; v[100:103] more K fragment addresses, v[180:182] more DMA offsets
 #define NNOP_DUO128_OPERANDS                                                                                                     \
     "+{v[0:15]}"(oacc[0][0]), "+{v[16:31]}"(oacc[0][1]), "+{v[32:47]}"(oacc[0][EB - 2]), "+{v[48:63]}"(oacc[0][EB - 1]),                  \
@@ -128,7 +141,8 @@ template <typename T, int E> constexpr int fa_fwd_duo_lds_bytes(bool masked) {
 // every fragment then feeds one MFMA and the per-iteration overheads are paid per 32 rows: ~8 % more cycles per row).
 template <typename T, int E, int MODE, int NZ = 2>
 __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
-    static_assert(sizeof(T) == 2 && ((E == 64 && (NZ == 1 || NZ == 2)) || (E == 128 && NZ == 1)), "16-bit element types; E = 64, or E = 128 with 32-row waves");
+    static_assert(sizeof(T) == 2 && ((E == 64 && (NZ == 1 || NZ == 2)) || (E == 128 && NZ == 1) || (E == 32 && NZ == 2)),
+                  "16-bit element types; E = 64, E = 128 with 32-row waves, E = 32 with 64-row waves");
     constexpr int RW = 32 * NZ, RB = 4 * RW;                  // query rows per wave / per workgroup
     using frag_t = typename Elem<T>::frag;
     using KImg   = RowImg<T, E>;
@@ -304,7 +318,9 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     const uint32_t v_lane = (uint32_t)VImg::lane_base(lane) - wave_off_v;
     // K(grp) and Q landed (every wave's pieces: barrier); K(grp+2) and V(grp) -- the NJK + NJV pieces issued last -- stay in flight: the
     // loop's first counted wait (end of V(grp)) retires them, in time for M(grp+2).  The Q fragments pass through the statement.
-    if constexpr (E == 128)
+    if constexpr (E == 32)
+        asm volatile("s_waitcnt vmcnt(%c[n])\n\ts_barrier" : "+v"(qw[0][0]), "+v"(qw[0][KS - 1]), "+v"(qw[NZ - 1][0]), "+v"(qw[NZ - 1][KS - 1]) : [n] "n"(NJK + NJV) : "memory");
+    else if constexpr (E == 128)
         asm volatile("s_waitcnt vmcnt(%c[n])\n\ts_barrier"
                      : "+v"(qw[0][0]), "+v"(qw[0][1]), "+v"(qw[0][2]), "+v"(qw[0][3]), "+v"(qw[0][KS - 4]), "+v"(qw[0][KS - 3]), "+v"(qw[0][KS - 2]),
                        "+v"(qw[0][KS - 1])
@@ -317,14 +333,22 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     else
         asm volatile("s_waitcnt vmcnt(%c[n])\n\ts_barrier" : "+v"(qw[0][0]), "+v"(qw[0][1]), "+v"(qw[0][2]), "+v"(qw[0][3]) : [n] "n"(NJK + NJV) : "memory");
     // the fragments (16-deep steps of E) as 16-register tuples: v[64:79], v[80:95] = query blocks 0, 1 at E = 64 / steps 0-3, 4-7 at E = 128
-    constexpr int NQT = NZ * KS / 4;
+    // (E = 32: two fragments per query block, in the first half of that block's tuple)
+    constexpr int NQT = E == 32 ? NZ : NZ * KS / 4;
     f32x16 qf[NQT];
+    if constexpr (E == 32) {
 #pragma unroll
-    for (int z = 0; z < NZ; ++z)
+        for (int z = 0; z < NZ; ++z)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+            for (int i = 0; i < 16; ++i) qf[z][i] = i < 4 * KS ? qw[z][(i >> 2) % KS][i & 3] : 0.f;
+    } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) qf[(z * KS + ks) / 4][4 * (ks & 3) + i] = qw[z][ks][i];
+        for (int z = 0; z < NZ; ++z)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qf[(z * KS + ks) / 4][4 * (ks & 3) + i] = qw[z][ks][i];
+    }
 #if NNOP_DUO_STAMP
     stamp[2] = __builtin_amdgcn_s_memtime();
     stamp[3] = __builtin_amdgcn_s_memrealtime();
@@ -347,7 +371,7 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
     f32x4 mstate = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};       // m2[0..1] (exponent reference), mt[0..1] (true row max)
     typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
     u32x8 vconst;
-    vconst[0] = k_voff[0]; vconst[1] = k_voff[1]; vconst[2] = v_voff; vconst[3] = k_lane; vconst[4] = v_lane;
+    vconst[0] = k_voff[0]; vconst[1] = k_voff[NJK > 1 ? 1 : 0]; vconst[2] = v_voff; vconst[3] = k_lane; vconst[4] = v_lane;
     vconst[5] = (uint32_t)qlim[0]; vconst[6] = (uint32_t)qlim[1]; vconst[7] = (uint32_t)(4 * h);
     // the loop's scalar state (wave-uniform: hipcc hands them over in scalar registers)
     int s_t = grp, s_h = n_tiles + 2, s_nlive = n_live, s_cq0 = causal_q0;
@@ -378,7 +402,15 @@ __global__ __launch_bounds__(512) void fa_fwd_duo_kernel(const FwdParams p) {
 #define NNOP_DUO_PRIO_ARGS "", "", "", ""
 #endif
 #define NNOP_DUO_X(M, ...) M(__VA_ARGS__)
-    if constexpr (NZ == 2) {
+    if constexpr (E == 32) {
+        if constexpr (std::is_same<T, __bf16>::value) {
+            if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO32_LOOP_MASKED, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO32_OPERANDS);
+            else asm volatile(NNOP_DUO_X(NNOP_DUO32_LOOP_PLAIN, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO32_OPERANDS);
+        } else {
+            if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO32_LOOP_MASKED, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO32_OPERANDS);
+            else asm volatile(NNOP_DUO_X(NNOP_DUO32_LOOP_PLAIN, "f16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO32_OPERANDS);
+        }
+    } else if constexpr (NZ == 2) {
         if constexpr (std::is_same<T, __bf16>::value) {
             if constexpr (kGeneral) asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_MASKED, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);
             else asm volatile(NNOP_DUO_X(NNOP_DUO_LOOP_PLAIN, "bf16", NNOP_DUO_PRIO_ARGS) : NNOP_DUO_OPERANDS);

@@ -243,6 +243,15 @@ static inline int fwd_form_of(const nnop_fa_desc& d, int mode) {
         }
         if (fits && (w64 == 1 || (w64 < 0 && pays))) return kFormW64;
     }
+    if (b16 && E == 32 && mode != 2 && (mode == 0 || d.kl <= 64 * kMaxMaskTiles) && (long long)d.kl * E * 2 < (1LL << 32)) {
+        // E = 32: the two-waves-per-SIMD form with 64-row waves (fa_fwd_duo.hpp).  The softmax, not the matrix pipe, is the bound of every
+        // form at E = 32 (they take as long as at E = 64).  Measured (profiles/r04/duo32_sweep.log), grids of >= 256 blocks: masked mode
+        // 1.1-1.5x faster from KL = 1024 (causal L2048 H8 B8 61.2 -> 40.8 us, L4096 H8 B8 164 -> 125; key padding +2..12 %), plain mode
+        // +3..6 % from KL = 2048; smaller grids lose (the 32-row forms have twice the workgroups).  Knob kTuneFwdDuo.
+        const int duo = tune_get(kTuneFwdDuo);
+        const bool duo_pays = wg256 >= 256 && (mode == 1 ? d.kl >= 1024 : d.kl >= 2048);
+        if (duo >= 1 || (duo < 0 && duo_pays)) return kFormDuo;
+    }
     if (b16 && E <= 64) {
         // plain mode: 16-wave split-KV workgroups (4 waves per SIMD); measured 5-13 % faster than the 8-wave form from 64 to
         // 4096 workgroups.  Knob kTuneFwdSplit: 0 off, 1 / auto on.
@@ -263,6 +272,9 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     }
     if constexpr (sizeof(T) == 2 && E == 128) {
         if (form == kFormDuo) return mode == 0 ? launch_fwd_duo<T, E, 0, 1>(d, a, s) : launch_fwd_duo<T, E, 1, 1>(d, a, s);
+    }
+    if constexpr (sizeof(T) == 2 && E == 32) {
+        if (form == kFormDuo) return mode == 0 ? launch_fwd_duo<T, E, 0, 2>(d, a, s) : launch_fwd_duo<T, E, 1, 2>(d, a, s);
     }
     if constexpr (sizeof(T) == 2 && E == 64) {
         if (form == kFormDuo) {

@@ -66,7 +66,9 @@ def test_compiled_kernels_allocate_within_the_loops_register_map():
         got[(int(m.group(1)), int(m.group(2)), m.group(3))] = int(m.group(4))
     for m in re.finditer(r"\.set _ZN4nnop17fa_fwd_duo_kernelIDF16bLi128ELi(\d)ELi1EEEvNS_9FwdParamsE\.(num_vgpr|num_agpr|private_seg_size), (\d+)", text):
         got[(int(m.group(1)), 128, m.group(2))] = int(m.group(3))
-    for nz in (1, 2, 128):                                    # rows per wave / 32 at E = 64; the E = 128 loop
+    for m in re.finditer(r"\.set _ZN4nnop17fa_fwd_duo_kernelIDF16bLi32ELi(\d)ELi2EEEvNS_9FwdParamsE\.(num_vgpr|num_agpr|private_seg_size), (\d+)", text):
+        got[(int(m.group(1)), 32, m.group(2))] = int(m.group(3))
+    for nz in (1, 2, 128, 32):                                # rows per wave / 32 at E = 64; the E = 128 loop; the E = 32 loop
         assert got[(0, nz, "num_vgpr")] <= 256 and got[(1, nz, "num_vgpr")] <= 256 and got[(0, nz, "num_agpr")] == 0 and got[(1, nz, "num_agpr")] == 0, got
         # plain mode: nothing spilled; masked mode (persistent block loop around the statement): a few prologue / epilogue values park in
         # scratch around -- never inside -- the loop, once per block

@@ -21,12 +21,13 @@ class Shape:
         self.knob, self.E = knob, E
 
 
-@pytest.fixture(params=[(2, 64), (3, 64), (1, 128)], ids=["rows64", "rows32", "e128"])
+@pytest.fixture(params=[(2, 64), (3, 64), (1, 128), (1, 32)], ids=["rows64", "rows32", "e128", "e32"])
 def duo(request):
-    """the three generated loops.  E = 64, knob fwd_duo: 2 forces the 64-rows-per-wave form (256-row workgroups), 3 the 32-row one
+    """the four generated loops.  E = 64, knob fwd_duo: 2 forces the 64-rows-per-wave form (256-row workgroups), 3 the 32-row one
     (128-row workgroups, the loop without its z = 1 half, the partners splitting the epilogue by columns); 1 = on, the launcher picks
     the rows per wave from the grid.  E = 128: 32-row waves only (16 KiB tiles: 2 ring slots per key group, the LDS-DMA batch in the
-    vector phase, a barrier behind every phase)"""
+    vector phase, a barrier behind every phase).  E = 32: 64-row waves only (the E = 64 loop with two contraction steps and one column
+    block of O^T per query block)"""
     # suite time: fp16 and bf16 run the same generated loop (the type is one mnemonic suffix); the 32-row loops keep their fp16 repeats
     # in the plain / causal sweeps and the reproducibility test only
     dt = request.node.callspec.params.get("dt") if hasattr(request.node, "callspec") else None
@@ -69,6 +70,9 @@ def test_the_launcher_picks_the_form_where_it_measured_faster(pkg):
     # E = 128 (32-row waves only, slower per tile): while the 128-row blocks fit one round; two rounds in masked mode from KL = 2048
     assert f(mk(emb=128, ql=2048, kl=2048)) == "fa_fwd_duo_kernel" and f(mk(emb=128, ql=2048, kl=2048, batch=8)) == "fa_fwd_w64_kernel"
     assert f(mk(emb=128, causal=1, qh=8, kh=8, batch=2)) == "fa_fwd_duo_kernel" and f(mk(emb=128, causal=1, qh=8, kh=8, batch=4)) == "fa_fwd_w64_kernel"
+    # E = 32 (64-row waves): grids of >= 256 blocks, masked mode from KL = 1024, plain mode from KL = 2048
+    assert f(mk(emb=32)) == "fa_fwd_duo_kernel" and f(mk(emb=32, ql=2048, kl=2048)) != "fa_fwd_duo_kernel"
+    assert f(mk(emb=32, causal=1, ql=1024, kl=1024, qh=8, kh=8, batch=8)) == "fa_fwd_duo_kernel" and f(mk(emb=16)) != "fa_fwd_duo_kernel"
 
 
 def test_rows_per_wave_follow_the_grid(pkg, dev, tune):

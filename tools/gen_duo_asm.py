@@ -54,7 +54,7 @@ S = lambda z, kb: 112 + 32 * z + 16 * kb
 FR = lambda i: (176 + 4 * i if i < 4 else 224 + 4 * (i - 4)) if NZ == 2 else 144 + 4 * i      # NZ = 1: v[144:175], the z = 1 score tile's
 M2 = lambda z: 192 + z
 MT = lambda z: 194 + z
-KVO = lambda j: 196 + j if E == 64 else (196 if j == 0 else 179 + j)      # E = 128: pieces 1..3 in v[180:182], derived in front of the loop
+KVO = lambda j: 196 + j if E != 128 else (196 if j == 0 else 179 + j)     # E = 128: pieces 1..3 in v[180:182], derived in front of the loop
 VVO, KLANE, VLANE = 198, 199, 200
 QLIM = lambda z: 201 + z
 H4 = 203
@@ -109,14 +109,14 @@ def set_nz(nz, e=64):
     phase whose slots it overwrites, i.e. into the vector phase, with a barrier behind EVERY phase (the matrix phase is the longer one
     there: 36 MFMAs against 32 logits per lane, so the vector-phase wave has the idle issue slots the 8 LDS-DMA pieces cost)."""
     global NZ, RING, PF, E, KS, EB, NKF, NVF, NJK, NJV, TILE_SHIFT, ROWB, DMA_AT, SLOTS, SYNC
-    assert e == 64 or (e == 128 and nz == 1)
+    assert e == 64 or (e == 128 and nz == 1) or (e == 32 and nz == 2)
     NZ, E = nz, e
     RING, PF = (_RING2, _PF2) if nz == 2 else (8, 6)
     KS, EB = e // 16, e // 32
     NKF, NVF = KB * KS, 4 * EB
-    NJK = NJV = e // 32
-    TILE_SHIFT, ROWB = (13, 128) if e == 64 else (14, 256)
-    DMA_AT, SLOTS, SYNC = (_DMA64, _SLOTS64, _SYNC64) if e == 64 else ("v", 2, "two")
+    NJK = NJV = max(1, e // 32)
+    TILE_SHIFT, ROWB = {32: (12, 64), 64: (13, 128), 128: (14, 256)}[e]
+    DMA_AT, SLOTS, SYNC = (_DMA64, _SLOTS64, _SYNC64) if e != 128 else ("v", 2, "two")
 
 # the scale-and-shift of the logits (s c2 - m2) as v_pk_fma_f32 over register pairs (one instruction per two logits; the scale in the scalar
 # pair s[66:67], -m2 broadcast from one register of v[208:209] by op_sel) instead of one v_fma_f32 per logit.  Measured
@@ -547,7 +547,7 @@ def render():
              f"#define NNOP_DUO_SLOTS_PER_GROUP {SLOTS}      // ring slots per key group and ring (where the DMA batch is issued decides)\n"
              f"#define NNOP_DUO_VALU_SUMS {1 if SUMS == 'valu' else 0}            // 1: row sums by v_add_f32 in the vector phase (4 chains in v[248:251])\n"
              f"#define NNOP_DUO_SYNC_ONE {1 if SYNC == 'one' else 0}             // 1: one barrier per iteration, no barrier of group 1 in front of the statement\n"]
-    for nz, e in ((2, 64), (1, 64), (1, 128)):
+    for nz, e in ((2, 64), (1, 64), (1, 128), (2, 32)):
         set_nz(nz, e)
         for masked in (False, True):
             check_stream(loop(masked))
@@ -564,6 +564,10 @@ def render():
                  f"#define NNOP_DUO128_SLOTS_PER_GROUP {SLOTS}\n#define NNOP_DUO128_SYNC_ONE {1 if SYNC == 'one' else 0}\n")
     parts.append(as_macro("NNOP_DUO128_LOOP_PLAIN", loop(False)))
     parts.append(as_macro("NNOP_DUO128_LOOP_MASKED", loop(True)))
+    set_nz(2, 32)
+    parts.append("// E = 32, 64-row waves: the E = 64 loop with two contraction steps and one 32-column block of O^T per query block\n")
+    parts.append(as_macro("NNOP_DUO32_LOOP_PLAIN", loop(False)))
+    parts.append(as_macro("NNOP_DUO32_LOOP_MASKED", loop(True)))
     set_nz(2)
     parts.append("// profile builds (make DEV=1 VAR=-DNNOP_DUO_STAMP=1): the same loops with s_memtime ticks; the five accumulators leave in v[224:228]\n"
                  "#ifdef NNOP_DEV_BUILD")
