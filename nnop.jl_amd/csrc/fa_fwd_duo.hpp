@@ -1,5 +1,5 @@
 // fa_fwd_duo.hpp -- forward kernel, "two waves per SIMD in alternating phases" form (16-bit types; E = 64 with 64- or 32-row waves,
-// E = 128 with 32-row waves).  The text below describes the E = 64, 64-row form; the variants are at its end.
+// E = 128 with 32-row waves, E = 32 with 64-row waves).  The text below describes the E = 64, 64-row form; the variants are at its end.
 //
 // What `_flash_attention_fwd!` computes (src/attention.jl:1-131; its hot loop :49-121), fourth program form.  Why it exists: at
 // E = 64 one 32x32x16 MFMA covers only two score elements per lane, and each element costs one v_exp_f32 (8 cycles of the SIMD's
@@ -37,6 +37,8 @@
 //     NZ = 1, E = 64   the same loop without its z = 1 half: 32 rows per wave, 128 per workgroup -- for launches whose 256-row blocks
 //                      would leave CUs idle (fa_launch.hpp small_grid_prefers_32_row_waves).  The partners finish the same 32 rows, group 0
 //                      the first half of the columns and the residuals, group 1 the second.
+//     NZ = 2, E = 32   the E = 64 loop with two contraction steps and one column block of O^T per query block (8 + 8 + 8 MFMAs per tile against
+//                      the same 128 logits per lane: the vector phase is the bound outright); grids of >= 256 blocks.
 //     NZ = 1, E = 128  O^T is again 64 registers (32 rows x 128 columns), Q eight fragments; tiles of 16 KiB -> 2 ring slots per key group,
 //                      the LDS-DMA batch (8 pieces per wave) in the VECTOR phase behind the barrier that closes the matrix phase whose
 //                      slots it overwrites, a barrier behind every phase.  LDS-bound per tile (slower than fa_fwd_w64.hpp on grids that
