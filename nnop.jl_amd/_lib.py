@@ -58,7 +58,7 @@ DEBUG_SYMBOLS = ("nnop_debug_set", "nnop_debug_dev_build", "nnop_debug_fwd_form"
 FWD_FORMS = {0: "fa_fwd_kernel", 1: "fa_fwd_split_kernel", 2: "fa_fwd_w64_kernel", 3: "fa_fwd_generic_kernel", 4: "fa_fwd_duo_kernel"}
 # keys of nnop_debug_set == enum TuneKey (csrc/tuning.hpp)
 TUNE_KEYS = {"fwd_split": 0, "fwd_nw": 1, "fwd_w64": 2, "bwd_big7": 3, "norm_bwd_cap": 4, "bwd_nw": 5,
-             "fwd_exact_scale": 6, "bwd_w64": 7, "bwd_stages": 8, "fwd_persist": 9, "bwd_persist": 10, "fwd_duo": 11, "fwd_persist_asc": 12, "bwd_narrow": 13}
+             "fwd_exact_scale": 6, "bwd_w64": 7, "bwd_stages": 8, "fwd_persist": 9, "bwd_persist": 10, "fwd_duo": 11, "fwd_persist_asc": 12, "bwd_narrow": 13, "fwd_causal_alt": 14}
 
 
 class FaShard(C.Structure):

@@ -21,7 +21,7 @@ static void tune_init() {
     static const char* const names[kTuneCount] = {"NNOP_FWD_SPLIT", "NNOP_FWD_NW",       "NNOP_FWD_W64",
                                                   "NNOP_BWD_BIG7",  "NNOP_NORM_BWD_CAP", "NNOP_BWD_NW",
                                                   "NNOP_FWD_EXACT_SCALE", "NNOP_BWD_W64", nullptr, "NNOP_FWD_PERSIST", "NNOP_BWD_PERSIST",
-                                                  "NNOP_FWD_DUO", "NNOP_FWD_PERSIST_ASC", "NNOP_BWD_NARROW"};
+                                                  "NNOP_FWD_DUO", "NNOP_FWD_PERSIST_ASC", "NNOP_BWD_NARROW", "NNOP_FWD_CAUSAL_ALT"};
     // (kTuneBwdStages has no environment variable: it makes the backward INCOMPLETE -- a measurement aid that only the test hook
     // nnop_debug_set can switch on, csrc/nnop_debug.h)
     for (int k = 0; k < kTuneCount; ++k) {

@@ -27,6 +27,7 @@ enum TuneKey {
     kTuneFwdDuo,         // NNOP_FWD_DUO     two-waves-per-SIMD alternating-phase forward (fa_fwd_duo.hpp, 16-bit E = 64): 0 never, 1 wherever instantiated
     kTuneFwdPersistAsc,  // NNOP_FWD_PERSIST_ASC persistent forward: q-blocks of a column ascending (light first: 1) / descending (0)
     kTuneBwdNarrow,      // NNOP_BWD_NARROW  one-wave-per-SIMD backward with 32 stationary rows per wave (128-row workgroups): 0 never, 1 wherever instantiated
+    kTuneFwdCausalAlt,   // NNOP_FWD_CAUSAL_ALT  32-row forward, causal: alternate the q-block direction of consecutive columns (0 never, 1 whenever the XCD remap allows)
     kTuneCount
 };
 

@@ -139,3 +139,23 @@ def test_masked_keys_with_overflowing_values_do_not_leak(pkg, dev, dt, causal):
     assert_close("dk", np.where(live, dk.double().cpu().numpy(), 0.0), np.where(live, rk, 0.0), dt, sc, floor=True)
     assert_close("dv", np.where(live, dv.double().cpu().numpy(), 0.0), np.where(live, rv, 0.0), dt, sc, floor=True)
     assert (dk[dead[:, None, :].expand(B, KH, KL)] == 0).all() and (dv[dead[:, None, :].expand(B, KH, KL)] == 0).all()
+
+
+@pytest.mark.parametrize("dt,E", [("f32", 64), ("f32", 32), ("bf16", 16)])
+@pytest.mark.parametrize("QH,KH", [(8, 8), (8, 4)])
+def test_causal_block_order_of_the_32_row_forward_does_not_change_results(pkg, dev, tune, dt, E, QH, KH):
+    """csrc/fa_fwd_inst.hpp launch_fwd_cfg: under a causal mask every second column of an XCD's dispatch order may run its q-blocks
+    ascending (heavy blocks beside light ones on a CU; knob fwd_causal_alt) -- a permutation of which workgroup does which block, so the
+    outputs are bitwise those of the plain heaviest-first order, and right"""
+    d = make_inputs(131, 2, QH, KH, 1100, 1100, E, dt, dev, need_do=False)      # 16 columns: 2 per XCD (the chunked remap applies)
+    outs = []
+    for alt in (0, 1):
+        tune(fwd_causal_alt=alt, fwd_duo=0, fwd_w64=0)
+        o, ms, ls = pkg._flash_attention(d["q"], d["k"], d["v"], causal=True)
+        torch.cuda.synchronize()
+        outs.append((o, ms, ls))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    o_ref, ms_ref, _ = oracle_fwd(d, True)
+    assert_close("o", outs[1][0], o_ref, dt)
+    assert_close("ms", outs[1][1], ms_ref, dt)
