@@ -59,7 +59,8 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
         const int rep = d.qh / d.kh;
         const bool chunked = (cols / rep) % 8 == 0 && (cols / 8) % 2 == 0;
         const int knob = tune_get(kTuneFwdCausalAlt);
-        p.causal_alt = (d.causal && MODE != 2 && chunked && (knob == 1 || (knob < 0 && n_wg > cus && n_wg <= (rep == 1 ? 4 : 2) * cus))) ? 1 : 0;
+        // (E = 128: one workgroup per CU, nothing to pair)
+        p.causal_alt = (d.causal && MODE != 2 && E <= 64 && chunked && (knob == 1 || (knob < 0 && n_wg > cus && n_wg <= (rep == 1 ? 4 : 2) * cus))) ? 1 : 0;
     }
     int lds_launch = lds;
 #ifdef NNOP_DEV_BUILD

@@ -159,3 +159,13 @@ def test_causal_block_order_of_the_32_row_forward_does_not_change_results(pkg, d
     o_ref, ms_ref, _ = oracle_fwd(d, True)
     assert_close("o", outs[1][0], o_ref, dt)
     assert_close("ms", outs[1][1], ms_ref, dt)
+    # the 32-row backward kernels take the same switch (fp32, and 16-bit E <= 32 -- no one-wave-per-SIMD form there)
+    do = torch.randn_like(d["q"])
+    grads = []
+    for alt in (0, 1):
+        tune(fwd_causal_alt=alt, fwd_duo=0, fwd_w64=0, bwd_w64=0)
+        o, ms, ls = outs[0]
+        grads.append(pkg.grad_flash_attention(do, o, ms, ls, d["q"], d["k"], d["v"], None, causal=True)[:3])
+        torch.cuda.synchronize()
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
