@@ -64,7 +64,7 @@ struct BwdParams {
     void* dpair_s;
     int   QLp, KLp;
     int   persist_hx = 0;   // persistent form: heads of the column axis per XCD when they divide by 8 (fa_fwd.hpp), else 0
-    int   causal_alt = 0;   // fa_bwd_dkdv_kernel / fa_bwd_dq_kernel, causal: every second column of an XCD's dispatch order runs its blocks the other way round (fa_fwd_inst.hpp launch_fwd_cfg)
+    int   causal_alt = 0;   // fa_bwd_dkdv_kernel / fa_bwd_dq_kernel, causal: g > 0 -- every second run of g consecutive blocks of an XCD's dispatch order runs its blocks the other way round (fa_launch.hpp causal_alt_run)
     int   persist = 0;   // fa_bwd_w64_kernel: blocks per workgroup of the persistent form (grid = 256 workgroups), 0 = one block per workgroup
 };
 
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
     const int lin  = (kPair && !kStaged) ? xcd_remap_heads(bid, p.n_blk, p.KH, p.n_wg / p.KH)
                                          : xcd_remap_chunked(bid, p.n_wg, p.n_blk);      // chunk = one (batch, kv-head)
     int kblk = lin % p.n_blk;                  // (causal: block 0 sees every query -- ascending is heaviest first)
-    if (p.causal && p.causal_alt && (((bid >> 3) / p.n_blk) & 1) != 0) kblk = p.n_blk - 1 - kblk;
+    if (p.causal && p.causal_alt > 0 && (((bid >> 3) / p.causal_alt) & 1) != 0) kblk = p.n_blk - 1 - kblk;
     const int bk   = lin / p.n_blk;
     const int b    = bk / p.KH;
     const int kvh  = bk - b * p.KH;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 4 && E > 64) ? 1 : 2) void f
                                   : xcd_remap_chunked(bid, p.n_wg, p.n_blk * (p.QH / p.KH));
     int qblk = lin % p.n_blk;
     const int bh = lin / p.n_blk;
-    if (p.causal && !(p.causal_alt && (((bid >> 3) / p.n_blk) & 1) != 0)) qblk = p.n_blk - 1 - qblk;
+    if (p.causal && !(p.causal_alt > 0 && (((bid >> 3) / p.causal_alt) & 1) != 0)) qblk = p.n_blk - 1 - qblk;
     const int b = bh / p.QH;
     const int qh = bh - b * p.QH;
     const int kvh = qh / (p.QH / p.KH);

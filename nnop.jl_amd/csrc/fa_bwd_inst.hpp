@@ -28,16 +28,12 @@ template <typename T, int E> struct BwdCfg {
     static constexpr int BK    = (E > 64) ? 32 : 64;
 };
 
-// The forward's rule for causal launches of a few rounds (fa_fwd_inst.hpp launch_fwd_cfg: co-resident workgroups of consecutive columns
-// run their blocks in opposite directions): `cols` columns dealt to the XCDs in chunks of `rep`.  Knob kTuneFwdCausalAlt.
-// Only where two workgroups share a CU (E <= 64: the fp32 E = 128 kernels fill a CU alone, and there the alternate order is just a worse
-// list -- measured fp32 E128 L4096 H8 B2 causal backward 2606 -> 3763 us).
-static inline bool bwd_causal_alt(const nnop_fa_desc& d, long long n_wg, long long cols, int rep, bool pair) {
-    if (d.emb > 64) return false;
-    const long long cus = device_cu_count() > 0 ? device_cu_count() : 256;
-    const bool chunked = (cols / rep) % 8 == 0 && (cols / 8) % 2 == 0;
-    const int knob = tune_get(kTuneFwdCausalAlt);
-    return d.causal && !pair && chunked && (knob == 1 || (knob < 0 && n_wg > cus && n_wg <= (rep == 1 ? 4 : 2) * cus));
+// The forward's rule for causal launches of a few rounds (fa_launch.hpp causal_alt_run), only where two workgroups share a CU (E <= 64:
+// the fp32 E = 128 kernels fill a CU alone, and there the alternate order is just a worse list -- measured fp32 E128 L4096 H8 B2 causal
+// backward 2606 -> 3763 us).
+static inline int bwd_causal_alt(const nnop_fa_desc& d, long long n_wg, long long cols, int rep, int n_blk, bool pair) {
+    if (d.emb > 64 || pair) return 0;
+    return causal_alt_run(d.causal != 0, n_wg, cols, rep, n_blk);
 }
 
 template <typename T, int E, int NW, int BQ, int MODE>
@@ -53,7 +49,7 @@ static int launch_dkdv(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s)
     if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     pk.n_wg = (int)n_wg;
     if (n_wg * fa_bwd_split<T, E>() > 0x7fffffffLL) return NNOP_ERR_SHAPE;
-    pk.causal_alt = bwd_causal_alt(d, n_wg, (long long)d.kh * d.batch, 1, MODE >= 2) ? 1 : 0;
+    pk.causal_alt = bwd_causal_alt(d, n_wg, (long long)d.kh * d.batch, 1, pk.n_blk, MODE >= 2);
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg * fa_bwd_split<T, E>())), dim3(NW * 64), lds, s, pk);   // (fp32 E = 256: every block once per column slice)
     return NNOP_OK;
 }
@@ -71,7 +67,7 @@ static int launch_dq(const nnop_fa_desc& d, const BwdParams& p, hipStream_t s) {
     if (n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     pq.n_wg = (int)n_wg;
     if (n_wg * fa_bwd_split<T, E>() > 0x7fffffffLL) return NNOP_ERR_SHAPE;
-    pq.causal_alt = bwd_causal_alt(d, n_wg, (long long)d.qh * d.batch, d.qh / d.kh, MODE >= 2) ? 1 : 0;
+    pq.causal_alt = bwd_causal_alt(d, n_wg, (long long)d.qh * d.batch, d.qh / d.kh, pq.n_blk, MODE >= 2);
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_wg * fa_bwd_split<T, E>())), dim3(NW * 64), lds, s, pq);
     return NNOP_OK;
 }

@@ -90,7 +90,7 @@ struct FwdParams {
     int   persist_hx = 0;    // persistent form: heads per XCD when QH % 8 == 0 (the XCD's columns = those heads of every batch), else 0
     int   persist = 0;       // fa_fwd_w64_kernel: blocks per workgroup of the persistent form (grid = 256 workgroups), 0 = one block per workgroup
     int   persist_asc = 0;   // persistent form: q-blocks of a column in ASCENDING order (light blocks first), see fwd_persist_plan
-    int   causal_alt = 0;    // fa_fwd_kernel, causal: every second column of an XCD's dispatch order runs its q-blocks ascending (launch_fwd_cfg)
+    int   causal_alt = 0;    // fa_fwd_kernel, causal: g > 0 -- every second run of g consecutive blocks of an XCD's dispatch order (whole columns) runs its q-blocks ascending (launch_fwd_cfg)
 #ifdef NNOP_DEV_BUILD
     int   stagger = 0;       // experiment: s_sleep units for the odd co-resident workgroup (0 = off)
 #endif
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NW * 64, (QB == 2 || (sizeof(T) == 4 && E >= 256)) 
     const int bh = lin / p.n_qblk;
     // causal: heaviest q-blocks first -- except (causal_alt) in every second column of this XCD's dispatch order: the workgroups that
     // share a CU at the same time then come from a descending and an ascending column, heavy beside light
-    if (p.causal && !(p.causal_alt && (((((int)blockIdx.x >> 3) / p.n_qblk) & 1) != 0))) qblk = p.n_qblk - 1 - qblk;
+    if (p.causal && !(p.causal_alt > 0 && (((((int)blockIdx.x >> 3) / p.causal_alt) & 1) != 0))) qblk = p.n_qblk - 1 - qblk;
     const int b   = bh / p.QH;
     const int qh  = bh - b * p.QH;
     const int kvh = qh / (p.QH / p.KH);                    // cld(q_head, n_q_per_kv), 0-based

@@ -47,21 +47,12 @@ static int launch_fwd_cfg(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s
     if (n_wg <= 0 || n_wg > 0x7fffffffLL) return NNOP_ERR_SHAPE;
     p.n_wg = (int)n_wg;
     p.scale = (float)(1.0 / sqrt((double)E));        // T(inv(sqrt(QE))), src/attention.jl:154
-    // Causal launches of a few rounds: these kernels run 2 (and more) workgroups per CU side by side, and the dispatch order hands a CU
-    // the SAME q-block of consecutive columns -- two heavy blocks on one CU, two light ones on another (fp32 E64 L4096 H4 B4: causal
-    // 544 us = non-causal 531).  Alternating the direction of every second column pairs heavy with light: measured (round 4,
-    // profiles/r04/causal_alt.log) fp32 E64 L4096 H4 B4 545.6 -> 319.6 us, fp32 E32 301 -> 180, fp32 E16 233 -> 142, bf16 E16 69.8 -> 53.0,
-    // fp32 E64 L2048 H8 B8 (4 rounds) 473 -> 428; GQA at 4 rounds -5 %, 8 rounds and more -12 %.  Needs the chunked XCD remap
-    // (whole columns per XCD, an even number of them) -- otherwise, and on large grids (the dispatcher's dynamic order balances them and
-    // heaviest-first keeps the tail short), plain descending order.  Knob kTuneFwdCausalAlt: 0 never, 1 whenever the remap allows.
-    {
-        const long long cols = (long long)d.qh * d.batch, cus = device_cu_count() > 0 ? device_cu_count() : 256;
-        const int rep = d.qh / d.kh;
-        const bool chunked = (cols / rep) % 8 == 0 && (cols / 8) % 2 == 0;
-        const int knob = tune_get(kTuneFwdCausalAlt);
-        // (E = 128: one workgroup per CU, nothing to pair)
-        p.causal_alt = (d.causal && MODE != 2 && E <= 64 && chunked && (knob == 1 || (knob < 0 && n_wg > cus && n_wg <= (rep == 1 ? 4 : 2) * cus))) ? 1 : 0;
-    }
+    // Causal launches of a few rounds: pair heavy with light blocks on a CU (fa_launch.hpp causal_alt_run).  Measured (round 4,
+    // profiles/r04/causal_alt.log): fp32 E64 L4096 H4 B4 545.6 -> 319.6 us, fp32 E32 301 -> 180, fp32 E16 233 -> 142, bf16 E16 69.8 -> 53.0,
+    // fp32 E64 L2048 H8 B8 (4 rounds) 473 -> 428; GQA at 4 rounds -5 %, 8 rounds and more -12 % (the rule stops before).  Where ONE workgroup
+    // fills a CU there is nothing to pair (E = 128 with 8 waves; fp32 E = 128 with 4 waves fits two).
+    p.causal_alt = (MODE != 2 && (E <= 64 || (E == 128 && sizeof(T) == 4 && NW == 4)))
+                       ? causal_alt_run(d.causal != 0, n_wg, (long long)d.qh * d.batch, d.qh / d.kh, p.n_qblk) : 0;
     int lds_launch = lds;
 #ifdef NNOP_DEV_BUILD
     // experiments (make DEV=1 only): de-phase co-resident workgroups; pad LDS to limit workgroups per CU
@@ -325,6 +316,12 @@ static int launch_fwd_e(const nnop_fa_desc& d, const FwdArgs& a, hipStream_t s) 
     {
         const long long wg128 = (long long)((d.ql + 127) / 128) * d.qh * d.batch;
         if (d.causal && wg128 >= 512 && (E <= 64 || d.ql <= 2048)) nw = 4;
+    }
+    // fp32 E = 128 under a causal mask: two 4-wave workgroups fit a CU where one 8-wave workgroup does, and with the alternating block order
+    // (launch_fwd_cfg) they pair heavy with light: L4096 H8 B2 1019.6 -> 627.0 us.  Only where that order applies.
+    if constexpr (sizeof(T) == 4 && E == 128) {
+        const long long wg128 = (long long)((d.ql + 127) / 128) * d.qh * d.batch;
+        if (mode == 1 && causal_alt_run(d.causal != 0, wg128, (long long)d.qh * d.batch, d.qh / d.kh, (d.ql + 127) / 128) > 0) nw = 4;
     }
     if (E >= 128 && mode == 2) nw = 4;               // the E=128 pair-bias body: 4 waves per workgroup
     if (E >= 256) nw = 4;                            // E = 256: one form (it spills at the 256-register cap as it is)

@@ -101,6 +101,28 @@ inline int device_cu_count() {
     return v;
 }
 
+// Causal launches of a few rounds in the 32-row kernels, which run two workgroups per CU side by side: the dispatch order hands a CU the
+// SAME block index of two columns -- two heavy blocks on one CU, two light ones on another.  Returns g > 0 when runs of g consecutive
+// blocks of an XCD's dispatch order (whole columns; one "layer" of the XCD's CUs when a column is shorter) should alternate their
+// direction, so that the workgroups sharing a CU pair heavy with light; 0 = plain heaviest-first order.  `cols` columns of `n_blk`
+// blocks, dealt to the XCDs in chunks of `rep` columns (xcd_remap_chunked).  Knob kTuneFwdCausalAlt: 0 never, 1 whenever the layout allows.
+inline int causal_alt_run(bool causal, long long n_wg, long long cols, int rep, int n_blk) {
+    if (!causal || n_blk <= 0 || rep <= 0) return 0;
+    const long long cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    const int per_xcd = (int)(cus / 8);
+    if ((cols / rep) % 8 != 0) return 0;                         // the chunked remap does not apply: no whole columns per XCD
+    int g = 0;
+    if (n_blk == per_xcd) g = n_blk;                             // a column is one layer of the XCD's CUs: alternate whole columns
+    else if (n_blk < per_xcd && per_xcd % n_blk == 0) g = per_xcd;      // several columns per layer: alternate layers
+    // (a column longer than a layer pairs its own blocks j and j + per_xcd on a CU: alternating columns makes that worse -- measured
+    // fp32 E128 L8192 H8 B2, 4 waves: 2441 -> 3036 us)
+    if (g == 0 || (((cols / 8) * n_blk) / g) % 2 != 0) return 0;   // an even number of runs per XCD
+    const int knob = tune_get(kTuneFwdCausalAlt);
+    if (knob == 0) return 0;
+    if (knob == 1) return g;
+    return (n_wg > cus && n_wg <= (rep == 1 ? 4 : 2) * cus) ? g : 0;
+}
+
 // Do 128-row workgroups of 32-row waves beat 256-row workgroups of 64-row waves for `len` stationary rows x `cols` (batch x head)
 // columns?  The 32-row forms (fa_fwd_duo.hpp NZ = 1, BwdW64Shape NARROW) do ~0.62 of a 256-row block's work time per 128-row block
 // (one MFMA per fragment read), so they pay where they turn idle CUs into busy ones.  Measured on 256 CUs (profiles/r04/nz1_sweep.log,
